@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle helpers (rasterisation and morphology).
+
+Restates the OpenCV 4.7 primitives the reference mapper calls on the hot path
+(opencv-python==4.7.0.72 in the reference's environment.yaml; cv2 is absent from this
+image, so parity at this seam is UNPINNED):
+
+  * filled `cv2.circle` (mapper.py:737-743): integer midpoint circle of
+    modules/imgproc/src/drawing.cpp `Circle()`, fill branch -- every scan line between
+    the mirrored octant points is filled, clipped to the image.
+  * `cv2.erode` with a rectangular kernel, default anchor (kernel centre = size // 2) and
+    the default border (treated as +inf, i.e. ignored) (mapper.py:1134-1141).
+  * the 7x7 "same" convolution + clamp used as a dilation (mapper.py:1142-1152).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def disk_halfwidths(radius: int) -> np.ndarray:
+    """hw[k] = largest |dx| filled on the rows at vertical offset +-k from the centre."""
+    radius = int(radius)
+    hw = np.full(radius + 1, -1, dtype=np.int64)
+    err, dx, dy = 0, radius, 0
+    plus, minus = 1, 2 * radius - 1
+    while dx >= dy:
+        hw[dy] = max(hw[dy], dx)
+        hw[dx] = max(hw[dx], dy)
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:
+            err -= minus
+            dx -= 1
+            minus -= 2
+    return hw
+
+
+def disk_mask(shape, center_row: int, center_col: int, radius: int) -> np.ndarray:
+    """Boolean image equal to cv2.circle(zeros, (center_col, center_row), radius, 1, -1)."""
+    h, w = shape
+    out = np.zeros((h, w), dtype=bool)
+    hw = disk_halfwidths(radius)
+    for k in range(-int(radius), int(radius) + 1):
+        r = center_row + k
+        half = hw[abs(k)]
+        if r < 0 or r >= h or half < 0:
+            continue
+        c0, c1 = max(center_col - half, 0), min(center_col + half, w - 1)
+        if c0 <= c1:
+            out[r, c0 : c1 + 1] = True
+    return out
+
+
+def erode_rect(mask: np.ndarray, size: int) -> np.ndarray:
+    """Binary erosion by a size x size box anchored at (size//2, size//2); outside = set."""
+    h, w = mask.shape
+    a = size // 2
+    pad = np.ones((h + size, w + size), dtype=bool)
+    pad[a : a + h, a : a + w] = mask
+    out = np.ones((h, w), dtype=bool)
+    for i in range(size):
+        for j in range(size):
+            out &= pad[i : i + h, j : j + w]
+    return out
+
+
+def dilate_same(mask: np.ndarray, size: int) -> np.ndarray:
+    """Binary dilation equal to clamp(conv2d(mask, ones(size,size), padding='same'), 0, 1)."""
+    h, w = mask.shape
+    total = size - 1
+    lo = total // 2  # torch 'same': left = total // 2, right = total - left
+    pad = np.zeros((h + total, w + total), dtype=bool)
+    pad[lo : lo + h, lo : lo + w] = mask
+    out = np.zeros((h, w), dtype=bool)
+    for i in range(size):
+        for j in range(size):
+            out |= pad[i : i + h, j : j + w]
+    return out

@@ -1,0 +1,168 @@
+/*
+ * ssmap -- MI355X (gfx950) semantic-map fusion engine, C ABI.
+ *
+ * Drop-in boundary for the per-step map fusion of Semantic-Search's
+ * `SemanticMapper` (reference: sem_objnav/obj_nav/mapper.py).  The reference has no FFI
+ * layer: its boundary is the Python class, so each entry point below cites the Python
+ * method (file:line) whose work it takes over.  A Python host (ctypes) owns every map
+ * array as a device tensor and passes plain pointers; the engine allocates only its own
+ * per-frame scratch in ssmap_create().  No entry point throws; all return an
+ * ssmap_status code.  Nothing here synchronises the stream except ssmap_read_results().
+ *
+ * Layouts (all row-major, little-endian, device memory unless marked HOST):
+ *   frames   depth [E][H][W] f32 (mutated in place), logits/probs [E][C][H][W] f32,
+ *            semantic / semantic_gt [E][H][W] i32, semantic_unc / semantic_max_prob [E][H][W] f32
+ *   maps     semantic_map [Hm][Wm] u32, semantic_map_color [Hm][Wm][3] u8,
+ *            height_map [Hm][Wm] f32, gt_map [Hm][Wm] u32, unc_map [Hm][Wm][1] f32,
+ *            prob_map [Hm][Wm][C] f32 (avg_prob_seg_map or log_odds_seg_map),
+ *            weight_map [Hm][Wm][1] f32, goal_map / hits / views [Hm][Wm] f32,
+ *            background_map [Hm][Wm] u32            -- exactly the reference's arrays
+ *                                                     (mapper.py:205-255)
+ */
+#ifndef SSMAP_H
+#define SSMAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssmap_engine ssmap_engine;
+
+typedef enum ssmap_status {
+    SSMAP_OK = 0,
+    SSMAP_ERR_INVALID_ARG = 1,
+    SSMAP_ERR_HIP = 2,           /* a HIP runtime call failed; see ssmap_last_error() */
+    SSMAP_ERR_UNSUPPORTED = 3,
+    SSMAP_ERR_NOT_READY = 4      /* ssmap_step before every env was bound */
+} ssmap_status;
+
+/* Aggregation rule = the reference's `prob_aggregate` with the "height_map_" prefix
+ * stripped (mapper.py:145-166, 211-254); the prefix is `use_height_map` below. */
+typedef enum ssmap_rule {
+    SSMAP_RULE_DIRECT = 0,       /* probablistic_mapping=False          mapper.py:343-359 */
+    SSMAP_RULE_ARGMAX = 1,       /* argmax (+ filter_goal_prob)         mapper.py:412-447 */
+    SSMAP_RULE_GOAL_DECAY = 2,   /* goal_decay (+ filter_goal_prob)     mapper.py:364-411 */
+    SSMAP_RULE_AVG_PROB = 3,     /* avg_prob                            mapper.py:517-569 */
+    SSMAP_RULE_W_AVG_PROB = 4,   /* w_avg_prob   (weight 1 - entropy)   mapper.py:528-532 */
+    SSMAP_RULE_W2_AVG_PROB = 5,  /* w2_avg_prob  (weight 1 / entropy)   mapper.py:533-537 */
+    SSMAP_RULE_LOG_ODDS = 6,     /* log_odds                            mapper.py:570-603 */
+    SSMAP_RULE_HV = 7,           /* height_map_hv                       mapper.py:604-666 */
+    SSMAP_RULE_PROB_HV = 8       /* height_map_prob_hv                  mapper.py:667-727 */
+} ssmap_rule;
+
+/* Per-env status bits reported by ssmap_read_results(). */
+#define SSMAP_ENV_INDEX_ERROR 1u   /* a cell index below -dim was selected: the reference
+                                      raises IndexError at mapper.py:338 */
+
+#define SSMAP_MAX_CLASSES 256
+#define SSMAP_MAX_MAP_DIM 8192
+#define SSMAP_MAX_POOL 8
+
+/* Fixed for the life of an engine: SemanticMapper.__init__ arguments (mapper.py:49-72)
+ * plus the frame geometry. */
+typedef struct ssmap_config {
+    int32_t n_envs;              /* E: environments stepped per call */
+    int32_t img_h, img_w;        /* H, W of every frame */
+    int32_t n_classes;           /* C = seg_model_n_classes; 0 when no class tensor is used */
+    int32_t n_schema;            /* num_semantic_classes (9 for the ObjectNav schema) */
+    int32_t rule;                /* ssmap_rule */
+    int32_t use_height_map;      /* 1 for the "height_map_*" variants */
+    int32_t max_map_h, max_map_w;/* largest map any env will bind (sizes scratch) */
+    float   depth_min, depth_max;/* depth_range sentinels           mapper.py:282-283 */
+    double  fx, fy;              /* focal lengths of pointcloud()   mapper.py:21-25 */
+    double  pixel2meter;
+    double  height_cutoff_m;
+} ssmap_config;
+
+/* One environment's maps, bound after SemanticMapper.reset(map_bounds) allocated them
+ * (mapper.py:193-269).  Unused maps for the engine's rule may be NULL. */
+typedef struct ssmap_env_maps {
+    int32_t map_h, map_w;
+    double  lower[3];            /* map_bounds[:3] */
+    uint32_t *semantic_map;
+    uint8_t  *semantic_map_color;
+    float    *height_map;
+    uint32_t *gt_map;            /* == semantic_map when probablistic_mapping is False */
+    float    *unc_map;
+    float    *prob_map;
+    float    *weight_map;
+    float    *goal_map;
+    uint32_t *background_map;
+    float    *hits;
+    float    *views;
+} ssmap_env_maps;
+
+/* Attributes the reference's callers overwrite after construction
+ * (eval_objnav.py:118-137) -- re-sent whenever they change. */
+typedef struct ssmap_params {
+    float   entropy_threshold;
+    float   filter_goal_prob;    /* used only when use_filter != 0 */
+    int32_t use_filter;
+    float   goal_decay, goal_mark;
+    float   hv_ratio, hv_min_views;
+    double  hv_limit_obj_view_dist;
+    double  found_dist_m;        /* radius of the found disk = int(found_dist_m / pixel2meter) */
+} ssmap_params;
+
+/* One batch of frames (one per env) = the `obs` dicts of E update_map calls
+ * (mapper.py:279-313).  Device pointers; NULL where a key is absent. */
+typedef struct ssmap_frames {
+    float         *depth;              /* mutated in place like obs["depth"] */
+    const float   *logits;             /* raw network output; stage 1 runs when non-NULL */
+    const float   *probs;              /* obs["semantic_prob"], used when logits is NULL */
+    float          temperature;        /* divides logits (infer.py:97, 309) */
+    int32_t       *semantic;           /* obs["semantic"]: input, or stage-1 output */
+    float         *semantic_unc;       /* likewise */
+    float         *semantic_max_prob;  /* likewise */
+    const int32_t *semantic_gt;
+    const double  *agent_pose;         /* HOST [E][7]: x y z qw qx qy qz (task.py:190-193) */
+    const double  *camera_pose;        /* HOST [E][7] */
+    const int32_t *goal_sem_id;        /* HOST [E]: goal2sem_id[objectgoal][0] */
+} ssmap_frames;
+
+/* SemanticMapper.__init__ (mapper.py:49-191): validates the config, allocates scratch. */
+int ssmap_create(const ssmap_config *cfg, ssmap_engine **out);
+void ssmap_destroy(ssmap_engine *eng);
+
+/* map_seg_to_schema as a table (infer.py:133-138, 336-341): lut[c] for c in [0, C).
+ * pool_ids/pool_count: for schema ids 3..8 the model classes whose probabilities are
+ * summed into semantic_max_prob (infer.py:109-118, 318-327); pool_ids is [6][SSMAP_MAX_POOL]. */
+int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n,
+                     const int32_t *pool_ids, const int32_t *pool_count);
+/* color_pallete (mapper.py:102-105): n rows of RGB. */
+int ssmap_set_palette(ssmap_engine *eng, const uint8_t *rgb, int32_t n);
+int ssmap_set_params(ssmap_engine *eng, const ssmap_params *p);
+
+/* SemanticMapper.reset (mapper.py:193-269) for env `e`: binds freshly initialised maps. */
+int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps);
+
+/* SemanticMapper.update_map for all E envs, without the ego-map rendering
+ * (mapper.py:276-821): stages 1-5 enqueued on `stream` (a hipStream_t passed as void*). */
+int ssmap_step(ssmap_engine *eng, const ssmap_frames *frames, void *stream);
+
+/* Stage 1 alone: the softmax/entropy/confidence tail of predict()
+ * (infer.py:97-118, 302-327).  probs_out may be NULL. */
+int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature,
+                 int32_t *semantic, float *semantic_unc, float *semantic_max_prob,
+                 float *probs_out, void *stream);
+
+/* Waits for `stream`, then copies per-env results of the last step to HOST arrays [E]:
+ * found (1 = is_found True, 0 = None), status (SSMAP_ENV_* bits), n_updates (K). */
+int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status,
+                       int32_t *n_updates, void *stream);
+
+/* Device pointer to the last step's update list of env `e`: n_updates pairs
+ * (flat pixel index, flat map cell index) as int32[2], unordered. */
+int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev);
+
+/* Algorithmic bytes one ssmap_step moves per frame for the bound config (reads of every
+ * input element once + state touched once, K = winners of the last read step). */
+const char *ssmap_last_error(void);
+const char *ssmap_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSMAP_H */

@@ -1,0 +1,402 @@
+// Host side of the C ABI declared in include/ssmap.h: engine life cycle, per-step pose
+// preparation (mapper.py:290-301) and kernel sequencing.  No torch types, no exceptions
+// across the boundary.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ssmap_internal.h"
+
+using namespace ssmap;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t err__ = (expr);                                                         \
+        if (err__ != hipSuccess)                                                           \
+            return fail(SSMAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__)); \
+    } while (0)
+
+constexpr int kPoseRing = 8;
+
+struct Quat { double w, x, y, z; };
+
+// Hamilton product, evaluated left to right like numpy-quaternion's C kernel.
+Quat qmul(const Quat &a, const Quat &b) {
+    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+                a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+                a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+
+// quaternion.from_rotation_vector: exp of the pure quaternion r/2.
+Quat qexp_half(double rx, double ry, double rz) {
+    const double x = rx / 2, y = ry / 2, z = rz / 2;
+    const double n = std::sqrt(x * x + y * y + z * z);
+    if (n > 1e-14) {
+        const double s = std::sin(n) / n, e = std::exp(0.0);
+        return Quat{e * std::cos(n), e * s * x, e * s * y, e * s * z};
+    }
+    return Quat{std::exp(0.0), 0, 0, 0};
+}
+
+// quaternion.as_rotation_matrix (array branch: entries divided by the Cayley norm).
+void qmatrix(const Quat &q, double *m) {
+    const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    m[0] = 1.0 - 2 * (q.y * q.y + q.z * q.z) / n;
+    m[1] = 2 * (q.x * q.y - q.z * q.w) / n;
+    m[2] = 2 * (q.x * q.z + q.y * q.w) / n;
+    m[3] = 2 * (q.x * q.y + q.z * q.w) / n;
+    m[4] = 1.0 - 2 * (q.x * q.x + q.z * q.z) / n;
+    m[5] = 2 * (q.y * q.z - q.x * q.w) / n;
+    m[6] = 2 * (q.x * q.z - q.y * q.w) / n;
+    m[7] = 2 * (q.y * q.z + q.x * q.w) / n;
+    m[8] = 1.0 - 2 * (q.x * q.x + q.y * q.y) / n;
+}
+
+int clamp_cell(double f) {
+    if (!(f > -1.0e9)) return -1000000000;
+    if (!(f < 1.0e9)) return 1000000000;
+    return (int)f;
+}
+
+// half widths of OpenCV's filled circle (drawing.cpp Circle(), fill branch)
+std::vector<int32_t> disk_halfwidths(int radius) {
+    std::vector<int32_t> hw(radius + 1, -1);
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hw[dy] = std::max(hw[dy], dx);
+        hw[dx] = std::max(hw[dx], dy);
+        ++dy;
+        err += plus;
+        plus += 2;
+        if (err > 0) { err -= minus; --dx; minus -= 2; }
+    }
+    return hw;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return SSMAP_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return SSMAP_OK;
+}
+
+}  // namespace
+
+struct ssmap_engine {
+    ssmap_config cfg{};
+    View view{};
+    std::vector<EnvState> envs;        // host mirror
+    EnvState *d_envs = nullptr;
+    PoseBlock *d_poses = nullptr;
+    PoseBlock *h_poses[kPoseRing] = {};   // pinned staging
+    hipEvent_t pose_done[kPoseRing] = {};
+    int ring = 0;
+    FrameHeader *d_hdr = nullptr;
+    std::vector<FrameHeader> h_hdr;
+    int32_t *d_lut = nullptr, *d_pool_ids = nullptr, *d_pool_count = nullptr, *d_disk = nullptr;
+    uint8_t *d_palette = nullptr;
+    int palette_rows = 0;
+    bool have_params = false, have_schema = false, have_palette = false;
+    Quat flip_cam{};
+    int device = 0;
+};
+
+extern "C" {
+
+const char *ssmap_last_error(void) { return g_error.c_str(); }
+const char *ssmap_version(void) { return "ssmap 0.1 (gfx950)"; }
+
+void ssmap_destroy(ssmap_engine *eng) {
+    if (!eng) return;
+    View &v = eng->view;
+    hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.winners);
+    hipFree(v.local_ids); hipFree(v.local_eroded);
+    for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
+    hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
+    hipFree(eng->d_disk); hipFree(eng->d_palette);
+    for (int i = 0; i < kPoseRing; ++i) {
+        if (eng->h_poses[i]) hipHostFree(eng->h_poses[i]);
+        if (eng->pose_done[i]) hipEventDestroy(eng->pose_done[i]);
+    }
+    delete eng;
+}
+
+int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
+    if (!cfg || !out) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    const ssmap_config &c = *cfg;
+    if (c.n_envs < 1 || c.img_h < 1 || c.img_w < 4 || (c.img_w % 4) != 0)
+        return fail(SSMAP_ERR_INVALID_ARG, "n_envs >= 1, img_h >= 1 and img_w a positive multiple of 4 are required");
+    if ((int64_t)c.img_h * c.img_w >= (1 << 30))
+        return fail(SSMAP_ERR_INVALID_ARG, "frame too large");
+    if (c.rule < SSMAP_RULE_DIRECT || c.rule > SSMAP_RULE_PROB_HV)
+        return fail(SSMAP_ERR_INVALID_ARG, "Invalid prob_aggregate");
+    const bool prob_rule = c.rule >= SSMAP_RULE_AVG_PROB && c.rule <= SSMAP_RULE_LOG_ODDS;
+    // the class tensor lives in LDS as [C][257] floats next to 2 KiB of bookkeeping
+    const int max_classes = (160 * 1024 - 4096) / (257 * 4);
+    if (c.n_classes < 0 || c.n_classes > max_classes || (prob_rule && c.n_classes < 1))
+        return fail(SSMAP_ERR_UNSUPPORTED, "n_classes must be in [1, 155] for the probability rules");
+    if (c.max_map_h < 1 || c.max_map_w < 1 || c.max_map_h > SSMAP_MAX_MAP_DIM || c.max_map_w > SSMAP_MAX_MAP_DIM)
+        return fail(SSMAP_ERR_INVALID_ARG, "map dimensions must be in [1, 8192]");
+    if ((c.rule == SSMAP_RULE_HV || c.rule == SSMAP_RULE_PROB_HV) && !c.use_height_map)
+        return fail(SSMAP_ERR_INVALID_ARG, "Invalid prob_aggregate");
+    if (c.rule == SSMAP_RULE_LOG_ODDS && c.use_height_map && c.n_schema != 9)
+        return fail(SSMAP_ERR_INVALID_ARG, "Invalid num_semantic_classes for height_map_log_odds aggregation");
+    if (!(c.pixel2meter > 0) || !(c.fx > 0) || !(c.fy > 0))
+        return fail(SSMAP_ERR_INVALID_ARG, "pixel2meter, fx, fy must be positive");
+
+    ssmap_engine *eng = new (std::nothrow) ssmap_engine();
+    if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "out of host memory");
+    eng->cfg = c;
+    HIP_TRY(hipGetDevice(&eng->device));
+    eng->flip_cam = qexp_half(M_PI, 0.0, 0.0);
+    eng->envs.assign(c.n_envs, EnvState{});
+    eng->h_hdr.assign(c.n_envs, FrameHeader{});
+
+    View &v = eng->view;
+    v.E = c.n_envs; v.H = c.img_h; v.W = c.img_w; v.N = c.img_h * c.img_w; v.C = c.n_classes;
+    v.n_schema = c.n_schema; v.rule = c.rule; v.use_height = c.use_height_map;
+    v.depth_min = c.depth_min; v.depth_max = c.depth_max;
+    v.fx = c.fx; v.fy = c.fy; v.p2m = c.pixel2meter;
+    const size_t EN = (size_t)v.E * v.N;
+    int rc = SSMAP_OK;
+#define TRY_ALLOC(call) do { rc = (call); if (rc != SSMAP_OK) { ssmap_destroy(eng); return rc; } } while (0)
+    TRY_ALLOC(dev_alloc(&eng->d_envs, (size_t)v.E));
+    TRY_ALLOC(dev_alloc(&eng->d_poses, (size_t)v.E));
+    TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
+    TRY_ALLOC(dev_alloc(&v.cellid, EN));
+    TRY_ALLOC(dev_alloc(&v.horder, EN));
+    if (prob_rule) TRY_ALLOC(dev_alloc(&v.target, EN));
+    TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
+    if (c.rule == SSMAP_RULE_GOAL_DECAY) {
+        v.local_stride = 4ll * c.max_map_h * c.max_map_w;
+        TRY_ALLOC(dev_alloc(&v.local_ids, (size_t)v.E * v.local_stride));
+        TRY_ALLOC(dev_alloc(&v.local_eroded, (size_t)v.E * v.local_stride));
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c.rule == SSMAP_RULE_HV || c.rule == SSMAP_RULE_PROB_HV) TRY_ALLOC(dev_alloc(&v.overlay[i], EN));
+        TRY_ALLOC(dev_alloc(&v.overlay_count[i], (size_t)v.E));
+        hipMemset(v.overlay_count[i], 0, sizeof(uint32_t) * v.E);
+    }
+    TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
+    TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
+    TRY_ALLOC(dev_alloc(&eng->d_pool_count, (size_t)6));
+    hipMemset(eng->d_pool_count, 0, 6 * sizeof(int32_t));
+    hipMemset(eng->d_lut, 0, SSMAP_MAX_CLASSES * sizeof(int32_t));
+#undef TRY_ALLOC
+    for (int i = 0; i < kPoseRing; ++i) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&eng->h_poses[i]), sizeof(PoseBlock) * v.E) != hipSuccess ||
+            hipEventCreateWithFlags(&eng->pose_done[i], hipEventDisableTiming) != hipSuccess) {
+            ssmap_destroy(eng);
+            return fail(SSMAP_ERR_HIP, "pinned pose staging allocation failed");
+        }
+    }
+    v.envs = eng->d_envs; v.poses = eng->d_poses; v.hdr = eng->d_hdr;
+    v.lut = eng->d_lut; v.pool_ids = eng->d_pool_ids; v.pool_count = eng->d_pool_count;
+    v.cur_overlay = 0;
+    *out = eng;
+    return SSMAP_OK;
+}
+
+int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n, const int32_t *pool_ids,
+                     const int32_t *pool_count) {
+    if (!eng || !lut || n < 1 || n > SSMAP_MAX_CLASSES) return fail(SSMAP_ERR_INVALID_ARG, "bad schema table");
+    if (eng->cfg.n_classes && n != eng->cfg.n_classes) return fail(SSMAP_ERR_INVALID_ARG, "schema table length != n_classes");
+    for (int i = 0; i < n; ++i)
+        if (lut[i] < 0 || lut[i] >= eng->cfg.n_schema + 3) return fail(SSMAP_ERR_INVALID_ARG, "schema id out of range");
+    HIP_TRY(hipMemcpy(eng->d_lut, lut, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (pool_ids && pool_count) {
+        for (int g = 0; g < 6; ++g) {
+            if (pool_count[g] < 0 || pool_count[g] > SSMAP_MAX_POOL) return fail(SSMAP_ERR_INVALID_ARG, "pool too long");
+            for (int k = 0; k < pool_count[g]; ++k)
+                if (pool_ids[g * SSMAP_MAX_POOL + k] < 0 || pool_ids[g * SSMAP_MAX_POOL + k] >= n)
+                    return fail(SSMAP_ERR_INVALID_ARG, "pool class out of range");
+        }
+        HIP_TRY(hipMemcpy(eng->d_pool_ids, pool_ids, 6 * SSMAP_MAX_POOL * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(eng->d_pool_count, pool_count, 6 * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    eng->have_schema = true;
+    return SSMAP_OK;
+}
+
+int ssmap_set_palette(ssmap_engine *eng, const uint8_t *rgb, int32_t n) {
+    if (!eng || !rgb || n < eng->cfg.n_schema + 2) return fail(SSMAP_ERR_INVALID_ARG, "palette too short");
+    if (eng->d_palette) { hipFree(eng->d_palette); eng->d_palette = nullptr; }
+    int rc = dev_alloc(&eng->d_palette, (size_t)3 * n);
+    if (rc != SSMAP_OK) return rc;
+    HIP_TRY(hipMemcpy(eng->d_palette, rgb, 3 * n, hipMemcpyHostToDevice));
+    eng->view.palette = eng->d_palette;
+    eng->palette_rows = n;
+    eng->have_palette = true;
+    return SSMAP_OK;
+}
+
+int ssmap_set_params(ssmap_engine *eng, const ssmap_params *p) {
+    if (!eng || !p) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    const int radius = (int)(p->found_dist_m / eng->cfg.pixel2meter);
+    if (radius < 0 || radius > 4096) return fail(SSMAP_ERR_INVALID_ARG, "found_dist_m out of range");
+    if (!eng->have_params || radius != eng->view.disk_radius) {
+        std::vector<int32_t> hw = disk_halfwidths(radius);
+        if (eng->d_disk) { hipFree(eng->d_disk); eng->d_disk = nullptr; }
+        int rc = dev_alloc(&eng->d_disk, hw.size());
+        if (rc != SSMAP_OK) return rc;
+        HIP_TRY(hipMemcpy(eng->d_disk, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        eng->view.disk_hw = eng->d_disk;
+        eng->view.disk_radius = radius;
+    }
+    eng->view.prm = *p;
+    eng->have_params = true;
+    return SSMAP_OK;
+}
+
+int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
+    if (!eng || !maps || e < 0 || e >= eng->cfg.n_envs) return fail(SSMAP_ERR_INVALID_ARG, "bad env index");
+    const ssmap_config &c = eng->cfg;
+    if (maps->map_h < 1 || maps->map_w < 1 || maps->map_h > c.max_map_h || maps->map_w > c.max_map_w)
+        return fail(SSMAP_ERR_INVALID_ARG, "map larger than max_map_h x max_map_w");
+    if (!maps->semantic_map || !maps->semantic_map_color || !maps->height_map)
+        return fail(SSMAP_ERR_INVALID_ARG, "semantic_map, semantic_map_color and height_map are required");
+    const int r = c.rule;
+    if (r != SSMAP_RULE_DIRECT && (!maps->gt_map || !maps->unc_map))
+        return fail(SSMAP_ERR_INVALID_ARG, "gt_map and unc_map are required in probabilistic mode");
+    if (r >= SSMAP_RULE_AVG_PROB && r <= SSMAP_RULE_LOG_ODDS && !maps->prob_map)
+        return fail(SSMAP_ERR_INVALID_ARG, "prob_map is required for this rule");
+    if (r >= SSMAP_RULE_AVG_PROB && r <= SSMAP_RULE_W2_AVG_PROB && !maps->weight_map)
+        return fail(SSMAP_ERR_INVALID_ARG, "weight_map is required for this rule");
+    if (r == SSMAP_RULE_GOAL_DECAY && !maps->goal_map)
+        return fail(SSMAP_ERR_INVALID_ARG, "goal_map is required for this rule");
+    if ((r == SSMAP_RULE_HV || r == SSMAP_RULE_PROB_HV) && (!maps->background_map || !maps->hits || !maps->views))
+        return fail(SSMAP_ERR_INVALID_ARG, "background_map, hits and views are required for this rule");
+    EnvState st{};
+    st.maps = *maps;
+    st.bound = 1;
+    eng->envs[e] = st;
+    HIP_TRY(hipMemcpy(eng->d_envs + e, &st, sizeof(EnvState), hipMemcpyHostToDevice));
+    const uint32_t zero = 0;
+    for (int i = 0; i < 2; ++i)
+        HIP_TRY(hipMemcpy(eng->view.overlay_count[i] + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+    return SSMAP_OK;
+}
+
+static int check_ready(ssmap_engine *eng) {
+    if (!eng->have_params) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_params was not called");
+    if (!eng->have_palette) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_palette was not called");
+    for (const EnvState &s : eng->envs)
+        if (!s.bound) return fail(SSMAP_ERR_NOT_READY, "an env has no maps bound (ssmap_bind_env)");
+    return SSMAP_OK;
+}
+
+int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
+    if (!eng || !f) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    int rc = check_ready(eng);
+    if (rc != SSMAP_OK) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const ssmap_config &c = eng->cfg;
+    View &v = eng->view;
+    const int r = c.rule;
+    const bool prob_rule = r >= SSMAP_RULE_AVG_PROB && r <= SSMAP_RULE_LOG_ODDS;
+    if (!f->depth || !f->agent_pose || !f->camera_pose || !f->goal_sem_id)
+        return fail(SSMAP_ERR_INVALID_ARG, "depth, agent_pose, camera_pose and goal_sem_id are required");
+    if (prob_rule && !f->logits && !f->probs)
+        return fail(SSMAP_ERR_INVALID_ARG, "this rule needs logits or semantic_prob");
+    if ((prob_rule || f->logits) && !eng->have_schema)
+        return fail(SSMAP_ERR_NOT_READY, "ssmap_set_schema was not called");
+    if (f->logits && !(f->temperature > 0)) return fail(SSMAP_ERR_INVALID_ARG, "temperature must be positive");
+    if (f->logits && c.n_classes < 1) return fail(SSMAP_ERR_INVALID_ARG, "engine was created without classes");
+    if (!prob_rule) {
+        if (!f->semantic) return fail(SSMAP_ERR_INVALID_ARG, "semantic is required for this rule");
+        const bool needs_unc = (r == SSMAP_RULE_PROB_HV) || ((r == SSMAP_RULE_ARGMAX || r == SSMAP_RULE_GOAL_DECAY) && v.prm.use_filter);
+        if (needs_unc && !f->semantic_unc) return fail(SSMAP_ERR_INVALID_ARG, "semantic_unc is required for this rule");
+        const bool needs_maxp = (r == SSMAP_RULE_PROB_HV) || (r == SSMAP_RULE_HV && v.prm.use_filter);
+        if (needs_maxp && !f->semantic_max_prob) return fail(SSMAP_ERR_INVALID_ARG, "semantic_max_prob is required for this rule");
+    }
+    if (r != SSMAP_RULE_DIRECT && !f->semantic_gt) return fail(SSMAP_ERR_INVALID_ARG, "semantic_gt is required in probabilistic mode");
+
+    // ---- pose preparation on the host (a few hundred flops per env)
+    const int slot = eng->ring;
+    eng->ring = (eng->ring + 1) % kPoseRing;
+    HIP_TRY(hipEventSynchronize(eng->pose_done[slot]));
+    PoseBlock *pb = eng->h_poses[slot];
+    for (int e = 0; e < c.n_envs; ++e) {
+        const double *ag = f->agent_pose + 7 * e, *cam = f->camera_pose + 7 * e;
+        const ssmap_env_maps &mp = eng->envs[e].maps;
+        PoseBlock &b = pb[e];
+        qmatrix(qmul(Quat{cam[3], cam[4], cam[5], cam[6]}, eng->flip_cam), b.rot);
+        b.trans[0] = cam[0]; b.trans[1] = cam[1]; b.trans[2] = cam[2];
+        b.h_cut = cam[1] + c.height_cutoff_m;
+        b.agent[0] = ag[0]; b.agent[1] = ag[1]; b.agent[2] = ag[2];
+        b.robot_row = clamp_cell(std::floor((ag[2] - mp.lower[2]) / c.pixel2meter));
+        b.robot_col = clamp_cell(std::floor((ag[0] - mp.lower[0]) / c.pixel2meter));
+        b.goal_id = f->goal_sem_id[e];
+        b.pad = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(eng->d_poses, pb, sizeof(PoseBlock) * c.n_envs, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(eng->pose_done[slot], stream));
+
+    launch_begin_step(v, stream);
+    launch_geometry(v, *f, stream);
+    launch_winners(v, stream);
+    if (prob_rule) {
+        launch_stream(v, *f, true, nullptr, stream);
+    } else {
+        if (f->logits) launch_stream(v, *f, false, nullptr, stream);
+        launch_label_rules(v, *f, stream);
+    }
+    launch_found(v, stream);
+    HIP_TRY(hipGetLastError());
+    v.cur_overlay ^= 1;
+    return SSMAP_OK;
+}
+
+int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature, int32_t *semantic,
+                 float *semantic_unc, float *semantic_max_prob, float *probs_out, void *stream_v) {
+    if (!eng || !logits) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    if (!eng->have_schema) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_schema was not called");
+    if (eng->cfg.n_classes < 1 || !(temperature > 0)) return fail(SSMAP_ERR_INVALID_ARG, "bad class count or temperature");
+    ssmap_frames f{};
+    f.logits = logits;
+    f.temperature = temperature;
+    f.semantic = semantic;
+    f.semantic_unc = semantic_unc;
+    f.semantic_max_prob = semantic_max_prob;
+    launch_stream(eng->view, f, false, probs_out, reinterpret_cast<hipStream_t>(stream_v));
+    HIP_TRY(hipGetLastError());
+    return SSMAP_OK;
+}
+
+int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status, int32_t *n_updates, void *stream_v) {
+    if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipMemcpyAsync(eng->h_hdr.data(), eng->d_hdr, sizeof(FrameHeader) * eng->cfg.n_envs,
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int e = 0; e < eng->cfg.n_envs; ++e) {
+        if (found) found[e] = eng->h_hdr[e].found;
+        if (status) status[e] = eng->h_hdr[e].status;
+        if (n_updates) n_updates[e] = (int32_t)eng->h_hdr[e].n_winners;
+    }
+    return SSMAP_OK;
+}
+
+int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev) {
+    if (!eng || !pairs_dev || e < 0 || e >= eng->cfg.n_envs) return fail(SSMAP_ERR_INVALID_ARG, "bad env index");
+    *pairs_dev = eng->view.winners + 2ll * e * eng->view.N;
+    return SSMAP_OK;
+}
+
+}  // extern "C"

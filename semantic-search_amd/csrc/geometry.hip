@@ -1,0 +1,301 @@
+// Stages 2 and 3 of the fusion path for gfx950:
+//   k_begin_step  resets the per-env frame headers
+//   k_geometry    depth -> world point -> map cell + height, one pass over the depth image
+//                 (mapper.py:279-283 sentinels, :18-32 pointcloud, :305-311 rotate/translate,
+//                  :851-863 world2map, :319-329 masks)
+//   k_winners     tallest point per cell, ties -> lowest pixel index (mapper.py:331), then
+//                 the height / depth / bounds filter (mapper.py:333-335)
+//
+// This file is compiled with -ffp-contract=off: the float64 geometry must round exactly
+// like the CPU statement of the same formulas (explicit fma only where written).
+#include "ssmap_internal.h"
+
+namespace ssmap {
+
+__global__ void k_begin_step(View v) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.E) return;
+    FrameHeader h;
+    h.rmin = h.cmin = h.wrmin = h.wcmin = 0x7FFFFFFF;
+    h.rmax = h.cmax = h.wrmax = h.wcmax = (int32_t)0x80000000;
+    h.min_invalid_pixel = kNoPixel;
+    h.n_winners = 0;
+    h.status = 0;
+    h.found = 0;
+    h.any_goal = 0;
+    h.n_overlay = 0;
+    h.pad[0] = h.pad[1] = 0;
+    v.hdr[e] = h;
+    v.overlay_count[v.cur_overlay][e] = 0;
+}
+
+__device__ inline int wave_min(int x) {
+    for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ inline int wave_max(int x) {
+    for (int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ inline unsigned wave_minu(unsigned x) {
+    for (int o = 32; o > 0; o >>= 1) x = min(x, (unsigned)__shfl_xor((int)x, o));
+    return x;
+}
+
+// One thread = 4 horizontally adjacent pixels (W % 4 == 0 is checked on the host).
+__global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all,
+                                                  int write_target) {
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const PoseBlock &pb = v.poses[e];
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const int Hm = mp.map_h, Wm = mp.map_w;
+
+    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
+    unsigned min_inv = kNoPixel;
+    unsigned err = 0;
+
+    if (i0 < v.N) {
+        const int r = i0 / v.W;
+        const int c0 = i0 - r * v.W;
+        float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        bool dirty = false;
+        uint32_t ids[4];
+        unsigned long long hk[4];
+        const double half_w = (double)v.W / 2.0, half_h = (double)v.H / 2.0;
+        const double yr = (double)r - half_h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float dk = d[k];
+            if (dk == v.depth_min || dk == v.depth_max) { dk = 0.0f; dirty = true; }
+            d[k] = dk;
+            const bool ok = dk > 0.0f;
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (ok) {
+                z = (double)dk;
+                x = z * ((double)(c0 + k) - half_w) / v.fx;
+                y = z * yr / v.fy;
+            }
+            const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
+            const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
+            const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
+            const double fr = floor((wz - mp.lower[2]) / v.p2m);
+            const double fc = floor((wx - mp.lower[0]) / v.p2m);
+            uint32_t id = kDeadCell;
+            unsigned long long key = 0;
+            // comparisons in double so that huge or non-finite coordinates never reach a cast
+            const bool below_upper = fr < (double)Hm && fc < (double)Wm;
+            const bool above_lower = fr >= -(double)Hm && fc >= -(double)Wm;
+            const bool pass = ok && (wy < pb.h_cut);
+            if (below_upper && above_lower && wy == wy) {
+                const int row = (int)fr, col = (int)fc;
+                rmin = min(rmin, row); rmax = max(rmax, row);
+                cmin = min(cmin, col); cmax = max(cmax, col);
+                if (ok) {
+                    id = ((uint32_t)(row + kCoordBias) << kCoordBits) | (uint32_t)(col + kCoordBias);
+                    if (pass) id |= kUpdBit;
+                    key = order_f64(wy);
+                }
+            } else if (below_upper && !above_lower && pass) {
+                err |= SSMAP_ENV_INDEX_ERROR;   // index below -dim: numpy raises IndexError
+            }
+            if (!ok) min_inv = min(min_inv, (unsigned)(i0 + k));
+            ids[k] = id;
+            hk[k] = key;
+        }
+        if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4 *>(v.cellid + fbase + i0) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+        unsigned long long *hp = v.horder + fbase + i0;
+        *reinterpret_cast<ulonglong2 *>(hp) = make_ulonglong2(hk[0], hk[1]);
+        *reinterpret_cast<ulonglong2 *>(hp + 2) = make_ulonglong2(hk[2], hk[3]);
+        if (write_target) *reinterpret_cast<int4 *>(v.target + fbase + i0) = make_int4(-1, -1, -1, -1);
+    }
+
+    // block reduction of the bbox, the lowest invalid pixel and the error bits
+    __shared__ int s_red[4][6];
+    rmin = wave_min(rmin); rmax = wave_max(rmax);
+    cmin = wave_min(cmin); cmax = wave_max(cmax);
+    min_inv = wave_minu(min_inv);
+    err = (unsigned)wave_max((int)err);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
+        s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
+            cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
+            min_inv = min(min_inv, (unsigned)s_red[w][4]);
+            err |= (unsigned)s_red[w][5];
+        }
+        FrameHeader *h = v.hdr + e;
+        if (rmin <= rmax) {
+            atomicMin(&h->rmin, rmin); atomicMax(&h->rmax, rmax);
+            atomicMin(&h->cmin, cmin); atomicMax(&h->cmax, cmax);
+        }
+        if (min_inv != kNoPixel) atomicMin(&h->min_invalid_pixel, min_inv);
+        if (err) atomicOr(&h->status, err);
+    }
+}
+
+// One block = one table of kSlots consecutive cells of the frame's cell bounding box
+// (cells are numbered row-major inside the box).  Every block scans all cell ids of
+// its frame and keeps the pixels that fall into its table:
+//   phase a   table_h[slot] = max height image            (64-bit integer LDS max)
+//   phase b   table_i[slot] = min pixel index among the pixels that reach that max
+//   phase c   slots whose winner passes the filters are appended to the update list
+// Integer max / min are order independent, so the result is deterministic.
+__global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
+    __shared__ unsigned long long table_h[kSlots];
+    __shared__ unsigned int table_i[kSlots];
+    __shared__ unsigned int s_count, s_base;
+    __shared__ int s_box[4];
+
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    FrameHeader *hdr = v.hdr + e;
+    const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
+    if (rmin > rmax) return;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const int Hm = mp.map_h, Wm = mp.map_w;
+    const int bw = cmax - cmin + 1;
+    const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
+    const int nparts = (int)((ncell + kSlots - 1) >> kSlotShift);
+    const int rmin_b = rmin + kCoordBias, cmin_b = cmin + kCoordBias;
+
+    // the cell all invalid-depth pixels fall into (they sit at the camera position,
+    // mapper.py:28-31) and their common height
+    const unsigned min_inv = hdr->min_invalid_pixel;
+    long long inv_L = -1;
+    unsigned long long inv_key = 0;
+    if (min_inv != kNoPixel) {
+        const double fr = floor(((0.0 + pb.trans[2]) - mp.lower[2]) / v.p2m);
+        const double fc = floor(((0.0 + pb.trans[0]) - mp.lower[0]) / v.p2m);
+        if (fabs(fr) < 1.0e9 && fabs(fc) < 1.0e9) {
+            const int row = (int)fr, col = (int)fc;
+            if (row >= rmin && row <= rmax && col >= cmin && col <= cmax) {
+                inv_L = (long long)(row - rmin) * bw + (col - cmin);
+                inv_key = order_f64(0.0 + pb.trans[1]);
+            }
+        }
+    }
+
+    const uint4 *ids4 = reinterpret_cast<const uint4 *>(v.cellid + fbase);
+    const unsigned long long *hk = v.horder + fbase;
+    const int n4 = v.N >> 2;
+    int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
+
+    for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
+        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+        const bool own_inv = inv_L >= 0 && (int)(inv_L >> kSlotShift) == p;
+        if (own_inv && threadIdx.x == 0) table_h[inv_L & (kSlots - 1)] = inv_key;
+        __syncthreads();
+
+        // phase a
+        for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
+            const uint4 id4 = ids4[q];
+            const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t id = ids[k];
+                if (id == kDeadCell) continue;
+                const int rr = (int)((id >> kCoordBits) & kCoordMask) - rmin_b;
+                const int cc = (int)(id & kCoordMask) - cmin_b;
+                const int L = rr * bw + cc;
+                if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], hk[4 * q + k]);
+            }
+        }
+        __syncthreads();
+        // phase b
+        if (own_inv && threadIdx.x == 0) {
+            const int s = (int)(inv_L & (kSlots - 1));
+            if (table_h[s] == inv_key) table_i[s] = (min_inv << 1) | 1u;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
+            const uint4 id4 = ids4[q];
+            const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t id = ids[k];
+                if (id == kDeadCell) continue;
+                const int rr = (int)((id >> kCoordBits) & kCoordMask) - rmin_b;
+                const int cc = (int)(id & kCoordMask) - cmin_b;
+                const int L = rr * bw + cc;
+                if ((L >> kSlotShift) == p) {
+                    const int s = L & (kSlots - 1);
+                    if (hk[4 * q + k] == table_h[s])
+                        atomicMin(&table_i[s], ((unsigned)(4 * q + k) << 1) | ((id & kUpdBit) ? 0u : 1u));
+                }
+            }
+        }
+        __syncthreads();
+        // phase c: count, reserve, emit
+        unsigned mine = 0;
+        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) {
+            const unsigned w = table_i[s];
+            mine += (w != kNoPixel && !(w & 1u)) ? 1u : 0u;
+        }
+        if (mine) atomicAdd(&s_count, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base = s_count ? atomicAdd(&hdr->n_winners, s_count) : 0u;
+            s_count = 0;
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) {
+            const unsigned w = table_i[s];
+            if (w == kNoPixel || (w & 1u)) continue;
+            const long long L = ((long long)p << kSlotShift) + s;
+            const int row = (int)(L / bw) + rmin, col = (int)(L % bw) + cmin;
+            lrmin = min(lrmin, row); lrmax = max(lrmax, row);
+            lcmin = min(lcmin, col); lcmax = max(lcmax, col);
+            // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
+            const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
+            const int cell = wr * Wm + wc;
+            const int pix = (int)(w >> 1);
+            if (write_target) v.target[fbase + pix] = cell;
+            if (write_list) {
+                const unsigned pos = s_base + atomicAdd(&s_count, 1u);
+                int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
+                const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
+                *out = make_int2((int)word, cell);
+            }
+        }
+        __syncthreads();
+    }
+
+    // bbox of the update cells (goal_decay works on it, mapper.py:1117-1118)
+    lrmin = wave_min(lrmin); lrmax = wave_max(lrmax);
+    lcmin = wave_min(lcmin); lcmax = wave_max(lcmax);
+    if ((threadIdx.x & 63) == 0 && lrmin <= lrmax) {
+        atomicMin(&hdr->wrmin, lrmin); atomicMax(&hdr->wrmax, lrmax);
+        atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
+    }
+    (void)s_box;
+}
+
+void launch_begin_step(const View &v, hipStream_t s) {
+    hipLaunchKernelGGL(k_begin_step, dim3((v.E + 63) / 64), dim3(64), 0, s, v);
+}
+
+void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s) {
+    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
+    dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
+    hipLaunchKernelGGL(k_geometry, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
+}
+
+void launch_winners(const View &v, hipStream_t s) {
+    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
+    dim3 grid(kWinnerPartsPerEnv, v.E);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
+}
+
+}  // namespace ssmap

@@ -1,0 +1,340 @@
+// Stage 4 for the label rules and stage 5 (found decision).  One thread per update cell,
+// read from the unordered (pixel, cell) list the winner kernel wrote.
+//   direct / argmax (+filter)   mapper.py:343-359, 412-447
+//   hv / prob_hv                mapper.py:604-727
+//   goal_decay (+filter)        mapper.py:364-411 with _erode_goal_2d, mapper.py:1114-1161
+//   found decision              mapper.py:735-821
+// Compiled with -ffp-contract=off (the view-distance gate is float64 and must round like
+// numpy's sqrt(dx*dx + dz*dz)).
+#include "ssmap_internal.h"
+
+namespace ssmap {
+
+constexpr int kListBlocks = 64;      // blocks per env for list / bbox sweeps
+
+__device__ inline int occupancy_override(int id, float h, int use_height, int n_schema) {
+    if (!use_height || n_schema != 9) return id;
+    if (id == 0 || id == 1 || id == 2) {
+        if (h > 0.1f) return 2;
+        if (h != -INFINITY && h < 0.1f) return 1;
+    }
+    return id;
+}
+
+__device__ inline void paint(const ssmap_env_maps &mp, const uint8_t *palette, int cell, int id) {
+    const uint8_t *rgb = palette + 3 * id;
+    uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+    dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+}
+
+__device__ inline float raise_height(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
+                                     int64_t fbase, int pix, int cell) {
+    const double h = unorder_f64(v.horder[fbase + pix]);
+    const float hn = fmaxf(mp.height_map[cell], (float)(h - pb.agent[1]));
+    mp.height_map[cell] = hn;
+    return hn;
+}
+
+// hv rules rebuild semantic_map from background_map every frame (mapper.py:662, 723); the
+// engine keeps semantic_map == background_map except on the cells listed here, and undoes
+// last frame's list instead of copying the whole map.
+__global__ void k_hv_revert(View v) {
+    const int e = blockIdx.y;
+    const int prev = v.cur_overlay ^ 1;
+    const unsigned n = v.overlay_count[prev][e];
+    const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cell = list[i];
+        mp.semantic_map[cell] = mp.background_map[cell];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict__ semantic,
+                                               const float *__restrict__ unc,
+                                               const float *__restrict__ maxp,
+                                               const int32_t *__restrict__ gt) {
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    const FrameHeader *hdr = v.hdr + e;
+    const unsigned n = hdr->n_winners;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const int goal = pb.goal_id;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
+    const bool hv = v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV;
+
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 pc = list[i];
+        const uint32_t pw = (uint32_t)pc.x;
+        const int pix = (int)(pw & kPixMask);
+        const int cell = pc.y;
+        const float h = raise_height(v, mp, pb, fbase, pix, cell);
+        int id = semantic[fbase + pix];
+        const int raw = id;
+
+        if (v.rule == SSMAP_RULE_DIRECT) {
+            id = occupancy_override(id, h, v.use_height, v.n_schema);
+            mp.semantic_map[cell] = (uint32_t)id;
+            paint(mp, v.palette, cell, id);
+            continue;
+        }
+        mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
+
+        if (v.rule == SSMAP_RULE_ARGMAX) {
+            if (unc) mp.unc_map[cell] = unc[fbase + pix];
+            if (v.prm.use_filter && id == goal && (1.0f - unc[fbase + pix]) < v.prm.filter_goal_prob) id = 0;
+            id = occupancy_override(id, h, v.use_height, v.n_schema);
+            mp.semantic_map[cell] = (uint32_t)id;
+            paint(mp, v.palette, cell, id);
+            continue;
+        }
+        if (hv) {
+            const bool weighted = v.rule == SSMAP_RULE_PROB_HV;
+            if (weighted) mp.unc_map[cell] = unc[fbase + pix];
+            else if (v.prm.use_filter && id == goal && maxp[fbase + pix] < v.prm.filter_goal_prob) id = 0;
+            id = occupancy_override(id, h, v.use_height, v.n_schema);
+            if (id != goal) mp.background_map[cell] = (uint32_t)id;
+
+            bool gated = true;
+            if (v.prm.hv_limit_obj_view_dist > 0.0) {
+                // map2world of the UNWRAPPED cell (mapper.py:639-644, 865-874)
+                int row = cell / mp.map_w, col = cell - row * mp.map_w;
+                if (pw & kRowNegBit) row -= mp.map_h;
+                if (pw & kColNegBit) col -= mp.map_w;
+                const double dx = ((double)col * v.p2m + mp.lower[0]) - pb.agent[0];
+                const double dz = ((double)row * v.p2m + mp.lower[2]) - pb.agent[2];
+                gated = sqrt(dx * dx + dz * dz) < v.prm.hv_limit_obj_view_dist;
+            }
+            const float add = weighted ? maxp[fbase + pix] : 1.0f;
+            float views = mp.views[cell], hits = mp.hits[cell];
+            if (!weighted || gated) { views += add; mp.views[cell] = views; }
+            if (gated && raw == goal) { hits += add; mp.hits[cell] = hits; }
+            const bool show = gated && hits > 0.0f && views != INFINITY;
+            const int shown = show ? goal : (int)mp.background_map[cell];
+            mp.semantic_map[cell] = (uint32_t)shown;
+            paint(mp, v.palette, cell, shown);
+            if (show) {
+                const int cur = v.cur_overlay;
+                const unsigned pos = atomicAdd(&v.overlay_count[cur][e], 1u);
+                v.overlay[cur][(int64_t)e * v.N + pos] = cell;
+            }
+            continue;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- goal_decay
+__device__ inline bool gd_box(const FrameHeader *hdr, int &r0, int &c0, int &bh, int &bw) {
+    if (hdr->wrmin > hdr->wrmax) return false;
+    r0 = hdr->wrmin; c0 = hdr->wcmin;
+    bh = hdr->wrmax - r0 + 1; bw = hdr->wcmax - c0 + 1;
+    return true;
+}
+
+__global__ void k_gd_clear(View v) {
+    const int e = blockIdx.y;
+    int r0, c0, bh, bw;
+    if (!gd_box(v.hdr + e, r0, c0, bh, bw)) return;
+    uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
+    const int64_t n = (int64_t)bh * bw;
+    for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) local[i] = 0;
+}
+
+__global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const float *__restrict__ unc,
+                             const int32_t *__restrict__ gt) {
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    FrameHeader *hdr = v.hdr + e;
+    int r0, c0, bh, bw;
+    if (!gd_box(hdr, r0, c0, bh, bw)) return;
+    const unsigned n = hdr->n_winners;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const int goal = pb.goal_id;
+    uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 pc = list[i];
+        const uint32_t pw = (uint32_t)pc.x;
+        const int pix = (int)(pw & kPixMask);
+        const int cell = pc.y;
+        raise_height(v, mp, pb, fbase, pix, cell);
+        mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
+        int id = semantic[fbase + pix];
+        if (v.prm.use_filter && id == goal && (1.0f - unc[fbase + pix]) < v.prm.filter_goal_prob) id = 0;
+        int row = cell / mp.map_w, col = cell - row * mp.map_w;
+        if (pw & kRowNegBit) row -= mp.map_h;
+        if (pw & kColNegBit) col -= mp.map_w;
+        local[(int64_t)(row - r0) * bw + (col - c0)] = (uint8_t)(id + 1);
+        if (id == goal) hdr->any_goal = 1u;
+    }
+}
+
+// erosion of the goal mask by an n x n box anchored at n/2 with the outside counted as set
+__global__ void k_gd_erode(View v, int size) {
+    const int e = blockIdx.y;
+    const FrameHeader *hdr = v.hdr + e;
+    int r0, c0, bh, bw;
+    if (!gd_box(hdr, r0, c0, bh, bw) || !hdr->any_goal) return;
+    const uint8_t goal1 = (uint8_t)(v.poses[e].goal_id + 1);
+    const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
+    uint8_t *er = v.local_eroded + (int64_t)e * v.local_stride;
+    const int a = size / 2;
+    const int64_t n = (int64_t)bh * bw;
+    for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / bw), c = (int)(i - (int64_t)r * bw);
+        bool keep = true;
+        for (int dr = -a; dr < size - a && keep; ++dr) {
+            const int rr = r + dr;
+            if (rr < 0 || rr >= bh) continue;
+            for (int dc = -a; dc < size - a; ++dc) {
+                const int cc = c + dc;
+                if (cc < 0 || cc >= bw) continue;
+                if (local[(int64_t)rr * bw + cc] != goal1) { keep = false; break; }
+            }
+        }
+        er[i] = keep ? 1 : 0;
+    }
+}
+
+__global__ void k_gd_apply(View v, int dil) {
+    const int e = blockIdx.y;
+    const FrameHeader *hdr = v.hdr + e;
+    int r0, c0, bh, bw;
+    if (!gd_box(hdr, r0, c0, bh, bw)) return;
+    const bool any_goal = hdr->any_goal != 0;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const int goal = v.poses[e].goal_id;
+    const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
+    const uint8_t *er = v.local_eroded + (int64_t)e * v.local_stride;
+    const int lo = (dil - 1) / 2, hi = (dil - 1) - lo;
+    const int64_t n = (int64_t)bh * bw;
+    for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / bw), c = (int)(i - (int64_t)r * bw);
+        const int stored = local[i];
+        int id = stored ? stored - 1 : 0;
+        bool valid;
+        if (any_goal) {
+            bool grown = false;
+            for (int dr = -lo; dr <= hi && !grown; ++dr) {
+                const int rr = r + dr;
+                if (rr < 0 || rr >= bh) continue;
+                for (int dc = -lo; dc <= hi; ++dc) {
+                    const int cc = c + dc;
+                    if (cc < 0 || cc >= bw) continue;
+                    if (er[(int64_t)rr * bw + cc]) { grown = true; break; }
+                }
+            }
+            valid = grown || (id != goal && id != 0);
+        } else {
+            valid = stored != 0;
+        }
+        if (!valid) continue;
+        int row = r + r0, col = c + c0;
+        if (row < 0) row += mp.map_h;
+        if (col < 0) col += mp.map_w;
+        const int cell = row * mp.map_w + col;
+        const bool is_goal = id == goal;
+        float g = mp.goal_map[cell];
+        g = is_goal ? g + 1.0f : g * v.prm.goal_decay;
+        mp.goal_map[cell] = g;
+        if (is_goal) id = 0;
+        if (g > v.prm.goal_mark) id = goal;
+        id = occupancy_override(id, mp.height_map[cell], v.use_height, v.n_schema);
+        mp.semantic_map[cell] = (uint32_t)id;
+        paint(mp, v.palette, cell, id);
+    }
+}
+
+// ---------------------------------------------------------------- stage 5
+// One block per env sweeps the filled disk of radius r around the robot cell (the disk is
+// given by per-row half widths, the raster of OpenCV's filled circle, mapper.py:737-743).
+__global__ __launch_bounds__(256) void k_found(View v) {
+    const int e = blockIdx.x;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const int goal = pb.goal_id;
+    const int R = v.disk_radius, side = 2 * R + 1;
+    const int C = v.C;
+    const bool hv = v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV;
+    const bool avg = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_W2_AVG_PROB;
+    const float log_c = C > 0 ? logf((float)C) : 1.0f;
+    bool found = false;
+    for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
+        const int dr = i / side - R, dc = i % side - R;
+        const int half = v.disk_hw[dr < 0 ? -dr : dr];
+        if (half < 0 || dc < -half || dc > half) continue;
+        const int row = pb.robot_row + dr, col = pb.robot_col + dc;
+        if (row < 0 || row >= mp.map_h || col < 0 || col >= mp.map_w) continue;
+        const int cell = row * mp.map_w + col;
+        if (hv) {
+            const float views = mp.views[cell], hits = mp.hits[cell];
+            if (!(views > v.prm.hv_min_views && hits > 0.0f)) continue;
+            if (views == INFINITY) continue;
+            if (hits / views > v.prm.hv_ratio) {
+                found = true;
+            } else {   // rejected for good (mapper.py:763-772)
+                mp.views[cell] = INFINITY;
+                const int bg = (int)mp.background_map[cell];
+                mp.semantic_map[cell] = (uint32_t)bg;
+                const uint8_t *rgb = v.palette + 3 * bg;
+                uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+                dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+            }
+            continue;
+        }
+        if ((int)mp.semantic_map[cell] != goal) continue;
+        if (avg || v.rule == SSMAP_RULE_LOG_ODDS) {
+            const float *m = mp.prob_map + (int64_t)cell * C;
+            float ent;
+            if (avg) {
+                float s = 0.0f;
+                for (int c = 0; c < C; ++c) s += m[c];
+                float hs = 0.0f;
+                for (int c = 0; c < C; ++c) {
+                    const float x = m[c] / s;
+                    hs += x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
+                }
+                ent = hs / log_c;
+            } else {   // softmax of the log-odds first (mapper.py:805-812)
+                float mx = -INFINITY;
+                for (int c = 0; c < C; ++c) mx = fmaxf(mx, m[c]);
+                float s = 0.0f;
+                for (int c = 0; c < C; ++c) s += expf(m[c] - mx);
+                float s2 = 0.0f, hs = 0.0f;
+                for (int c = 0; c < C; ++c) s2 += expf(m[c] - mx) / s;
+                for (int c = 0; c < C; ++c) {
+                    const float x = (expf(m[c] - mx) / s) / s2;
+                    hs += x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
+                }
+                ent = hs / log_c;
+            }
+            if (ent < v.prm.entropy_threshold) found = true;
+        } else {
+            found = true;
+        }
+    }
+    if (found) v.hdr[e].found = 1;
+}
+
+void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
+    dim3 grid(kListBlocks, v.E), block(256);
+    if (v.rule == SSMAP_RULE_GOAL_DECAY) {
+        const int erode = (int)ceil(0.1 / v.p2m), dil = (int)ceil(0.2 / v.p2m);
+        hipLaunchKernelGGL(k_gd_clear, grid, block, 0, s, v);
+        hipLaunchKernelGGL(k_gd_scatter, grid, block, 0, s, v, f.semantic, f.semantic_unc, f.semantic_gt);
+        hipLaunchKernelGGL(k_gd_erode, grid, block, 0, s, v, erode);
+        hipLaunchKernelGGL(k_gd_apply, grid, block, 0, s, v, dil);
+        return;
+    }
+    if (v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV)
+        hipLaunchKernelGGL(k_hv_revert, grid, block, 0, s, v);
+    hipLaunchKernelGGL(k_label, grid, block, 0, s, v, f.semantic, f.semantic_unc, f.semantic_max_prob, f.semantic_gt);
+}
+
+void launch_found(const View &v, hipStream_t s) {
+    hipLaunchKernelGGL(k_found, dim3(v.E), dim3(256), 0, s, v);
+}
+
+}  // namespace ssmap

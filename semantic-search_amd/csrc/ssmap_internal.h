@@ -1,0 +1,103 @@
+// Internal definitions shared by the engine's translation units (host + device).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssmap.h"
+
+namespace ssmap {
+
+constexpr uint32_t kDeadCell = 0xFFFFFFFFu;   // pixel takes no part in the group-by
+constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+constexpr int kCoordBias = 8192;              // cell coordinates are stored biased by this
+constexpr int kCoordBits = 14;
+constexpr uint32_t kCoordMask = (1u << kCoordBits) - 1;
+constexpr uint32_t kUpdBit = 1u << 28;        // pixel passes height cut-off, depth and upper bounds
+constexpr uint32_t kRowNegBit = 1u << 30;     // update-list pixel word: the cell row was negative
+constexpr uint32_t kColNegBit = 1u << 31;     // ... the cell column was negative (numpy wrap)
+constexpr uint32_t kPixMask = (1u << 30) - 1;
+constexpr int kSlots = 8192;                  // cells per LDS winner table
+constexpr int kSlotShift = 13;
+constexpr int kGeomPixPerBlock = 1024;        // geometry kernel: 256 threads x 4 pixels
+constexpr int kWinnerThreads = 1024;
+constexpr int kWinnerPartsPerEnv = 16;        // blocks launched per env for the winner kernel
+
+// Per-env, per-step geometry constants: the host derives them from the two pose vectors
+// exactly as mapper.py:290-301 does (quaternion products, rotation matrix).
+struct PoseBlock {
+    double rot[9];        // R(q_cam * rotvec(pi,0,0)), row-major
+    double trans[3];      // camera position
+    double h_cut;         // camera y + height_cutoff_m
+    double agent[3];      // agent position
+    int32_t robot_row, robot_col;   // world2map(agent position)
+    int32_t goal_id;      // schema id of the goal
+    int32_t pad;
+};
+
+// Per-env scratch header, rewritten every step.
+struct FrameHeader {
+    int32_t rmin, rmax, cmin, cmax;       // bbox of all live pixels' cells (unwrapped)
+    int32_t wrmin, wrmax, wcmin, wcmax;   // bbox of the update cells (unwrapped)
+    uint32_t min_invalid_pixel;           // lowest flat index with depth <= 0
+    uint32_t n_winners;
+    uint32_t status;
+    int32_t found;
+    uint32_t any_goal;                    // goal_decay: some update pixel carries the goal id
+    uint32_t n_overlay;                   // hv: goal overlays written this step
+    uint32_t pad[2];
+};
+
+struct EnvState {
+    ssmap_env_maps maps;
+    uint32_t n_overlay_prev;   // unused on host; kept for alignment
+    uint32_t bound;
+};
+
+// Everything a kernel needs, passed by value.
+struct View {
+    int32_t E, H, W, N, C, n_schema, rule, use_height;
+    float depth_min, depth_max;
+    double fx, fy, p2m;
+    // scratch (device)
+    const EnvState *envs;
+    const PoseBlock *poses;
+    FrameHeader *hdr;
+    uint32_t *cellid;          // [E][N]
+    unsigned long long *horder;// [E][N] order-preserving image of the f64 height
+    int32_t *target;           // [E][N] flat map cell this pixel updates, or -1
+    int32_t *winners;          // [E][N][2] (pixel, cell) pairs, unordered
+    uint8_t *local_ids;        // goal_decay: [E][4*maxHm*maxWm] id+1 on the update bbox
+    uint8_t *local_eroded;     // goal_decay: same shape
+    int32_t *overlay[2];       // hv: [E][N] cells showing the goal overlay (prev / current)
+    uint32_t *overlay_count[2];// [E]
+    int32_t cur_overlay;       // which of the two lists is written this step
+    int64_t local_stride;      // bytes per env in local_ids
+    const int32_t *lut;        // [C] model class -> schema id
+    const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
+    const int32_t *pool_count; // [6]
+    const uint8_t *palette;    // [n][3]
+    const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
+    int32_t disk_radius;
+    ssmap_params prm;
+};
+
+__host__ __device__ inline unsigned long long order_f64(double h) {
+    h = h + 0.0;   // -0.0 -> +0.0 so that equal values have equal images
+    unsigned long long b = (unsigned long long)__builtin_bit_cast(long long, h);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double unorder_f64(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __builtin_bit_cast(double, (long long)b);
+}
+
+// launchers (defined in the .hip files)
+void launch_begin_step(const View &v, hipStream_t s);
+void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s);
+void launch_winners(const View &v, hipStream_t s);
+void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);
+void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
+void launch_found(const View &v, hipStream_t s);
+
+}  // namespace ssmap

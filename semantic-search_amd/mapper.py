@@ -1,0 +1,267 @@
+"""`SemanticMapper`: the reference's class interface over the HIP engine (one environment).
+
+Same constructor keywords, methods, late-mutable attributes and public arrays as
+sem_objnav/obj_nav/mapper.py:48-269, so the callers (`MappingObjNavEnv`, env.py:165-185,
+377, 403, 560; `eval_objnav`, eval_objnav.py:118-137) can construct it in place of the
+reference class.  Observations arrive as numpy arrays (one frame), are copied to the GPU,
+fused there, and the map arrays are copied back only when a caller reads them.
+
+Not built yet (returned as blank arrays of the reference's shapes): the ego-centric crops of
+`ego_map` (mapper.py:876-998), the path overlay (mapper.py:822-833) and the "stubborn" rule.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+
+_MAP_NAMES = ("semantic_map", "semantic_map_color", "height_map", "gt_map", "unc_map", "goal_map",
+              "log_odds_seg_map", "avg_prob_seg_map", "avg_prob_weight_map", "background_map",
+              "hits", "views")
+_RULE_ATTRS = ("entropy_threshold", "goal_decay", "goal_mark", "hv_ratio", "hv_min_views",
+               "hv_limit_obj_view_dist")
+
+
+class SemanticMapper:
+    def __init__(
+        self,
+        num_semantic_classes: int,
+        depth_hfov: float,
+        depth_range: Tuple[float, float],
+        egomap_small_side_m: float = 3.0,
+        egomap_large_side_m: float = 10.0,
+        egomap_size: Tuple[int, int] = (128, 128),
+        pixel2meter: float = 0.03,
+        aux_num_bins: int = 12,
+        aux_radius_m: float = 0.4,
+        aux_bin_m: float = 0.15,
+        path_width_m: float = 0.1,
+        height_cutoff_m: float = 0.1,
+        agent_draw_radius_m: float = 0.1,
+        entropy_threshold: float = 0.5,
+        probablistic_mapping: bool = False,
+        prob_aggregate: str = "height_map_argmax",
+        success_dist_m: float = 1.0,
+        seg_model_n_classes: Optional[int] = None,
+        filter_goal_prob: Optional[float] = None,
+        collect_nb_data: bool = False,
+        model_name: Optional[str] = None,
+        device: str = "cuda:0",
+    ):
+        self.pixel2meter = pixel2meter
+        self.depth_range = depth_range
+        self.depth_hfov = depth_hfov
+        self.aux_bin_number = aux_num_bins
+        self.bin_size = 360 / aux_num_bins
+        self.angle_to_bins = np.arange(self.bin_size, 360 + self.bin_size, self.bin_size)
+        self.egomap_size = egomap_size
+        self.egomap_small_crop = [int(egomap_small_side_m / pixel2meter)] * 2
+        self.egomap_large_crop = [int(egomap_large_side_m / pixel2meter)] * 2
+        self.path_width_px = int(path_width_m / pixel2meter)
+        self.agent_radius_px = int(agent_draw_radius_m / pixel2meter)
+        self.color_pallete = _engine.colormap(num_semantic_classes + 3)
+        self.path_color = np.array([128, 0, 128], dtype=np.uint8)
+        self.color_pallete[num_semantic_classes + 1] = self.path_color
+        self.path_id = num_semantic_classes + 1
+        self.height_cutoff_m = height_cutoff_m
+        self.probablistic_mapping = probablistic_mapping
+        self.num_semantic_classes = num_semantic_classes
+        self.prob_aggregate = prob_aggregate
+        self.found_dist_m = success_dist_m
+        if prob_aggregate in ("height_map_stubborn", "stubborn") or collect_nb_data:
+            raise NotImplementedError("the stubborn rule and NB-data collection are not built")
+        self._rule, self._use_height = _engine.split_rule(prob_aggregate, probablistic_mapping)
+        # rule constants exist only for the rule that uses them, as in the reference
+        # (mapper.py:145-169); callers test them with hasattr (eval_objnav.py:118-129)
+        if probablistic_mapping and self._rule in ("hv", "prob_hv"):
+            self.hv_limit_obj_view_dist = 0.0
+            self.hv_min_views = 10
+            self.hv_ratio = 0.5
+        elif probablistic_mapping and self._rule in _engine.PROB_RULES:
+            self.entropy_threshold = entropy_threshold
+        elif self._rule == "goal_decay":
+            self.goal_decay = 0.9
+            self.goal_mark = 2.0
+        if num_semantic_classes == 9:
+            self.goal2sem_id = np.array([3, 4, 5, 6, 7, 8])
+        elif num_semantic_classes in (41, 38):
+            self.goal2sem_id = np.array([3, 11, 14, 18, 22, 10])
+        self.map_seg_to_schema = None
+        self.objnav_to_sem_pred = None
+        self.sem_model_n_classes = seg_model_n_classes
+        self.filter_goal_prob = filter_goal_prob
+        self.collect_nb_data = collect_nb_data
+        self.found_idx = None
+        self.prev_pos_px = None
+        self.map_bounds = None
+        self._device = device
+        self._engine: Optional[_engine.MapEngine] = None
+        self._engine_key = None
+        self._host_cache: Dict[str, np.ndarray] = {}
+        self._bound = False
+        self._schema_sent = False
+        self.last_status = 0
+        self.last_n_updates = 0
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_engine(self, h: int, w: int):
+        rows, cols = _engine.map_size(self.map_bounds, self.pixel2meter)
+        key = (h, w)
+        eng = self._engine
+        if eng is None or self._engine_key != key or rows > eng.max_map_hw[0] or cols > eng.max_map_hw[1]:
+            if eng is not None:
+                eng.close()
+            eng = _engine.MapEngine(
+                1, (h, w), num_semantic_classes=self.num_semantic_classes, depth_hfov=self.depth_hfov,
+                depth_range=self.depth_range, pixel2meter=self.pixel2meter,
+                height_cutoff_m=self.height_cutoff_m, probablistic_mapping=self.probablistic_mapping,
+                prob_aggregate=self.prob_aggregate, seg_model_n_classes=self.sem_model_n_classes,
+                max_map_hw=(rows, cols), success_dist_m=self.found_dist_m, device=self._device)
+            self._engine, self._engine_key = eng, key
+            self._bound = False
+            self._schema_sent = False
+        if not self._bound:
+            eng.reset_env(0, self.map_bounds)
+            self._bound = True
+        if not self._schema_sent and self.sem_model_n_classes and self.map_seg_to_schema is not None:
+            # map_seg_to_schema is a callable on label arrays (env.py:183); probe it once
+            lut = np.asarray(self.map_seg_to_schema(np.arange(self.sem_model_n_classes)))
+            pools = None
+            if self.objnav_to_sem_pred is not None:
+                pools = {g: list(self.objnav_to_sem_pred[g]) for g in range(3, 9)
+                         if g in self.objnav_to_sem_pred}
+            eng.set_schema(lut, pools)
+            self._schema_sent = True
+        return eng
+
+    def _sync_params(self, eng):
+        p = eng.params
+        for name in _RULE_ATTRS + ("filter_goal_prob", "found_dist_m"):
+            if hasattr(self, name) and getattr(p, name) != getattr(self, name):
+                setattr(p, name, getattr(self, name))
+
+    # ------------------------------------------------------------------ reference interface
+    def reset(self, map_bounds: np.ndarray):
+        self.map_bounds = np.asarray(map_bounds)
+        self._bound = False
+        self._host_cache = {}
+        self.prev_pos_px = None
+        self.found_idx = None
+        if self._engine is not None:
+            rows, cols = _engine.map_size(self.map_bounds, self.pixel2meter)
+            if rows <= self._engine.max_map_hw[0] and cols <= self._engine.max_map_hw[1]:
+                self._engine.reset_env(0, self.map_bounds)
+                self._bound = True
+
+    def update_map(self, obs: Dict[str, np.ndarray], auxillary_angle=None):
+        depth = obs["depth"]
+        h, w = depth.shape
+        eng = self._ensure_engine(h, w)
+        self._sync_params(eng)
+        dev = eng.device
+        goal_id = int(self.goal2sem_id[obs["objectgoal"]][0])
+
+        def up(key, dtype):
+            if key not in obs or obs[key] is None:
+                return None
+            return torch.from_numpy(np.ascontiguousarray(obs[key], dtype=dtype)).to(dev).unsqueeze(0).contiguous()
+
+        d_depth = up("depth", np.float32)
+        kwargs = {}
+        if self.probablistic_mapping:
+            kwargs["semantic_gt"] = up("semantic_gt", np.int32)
+            if self._rule in _engine.PROB_RULES:
+                kwargs["probs"] = up("semantic_prob", np.float32)
+            else:
+                kwargs["semantic"] = up("semantic", np.int32)
+                kwargs["semantic_unc"] = up("semantic_unc", np.float32)
+                kwargs["semantic_max_prob"] = up("semantic_max_prob", np.float32)
+        else:
+            kwargs["semantic"] = up("semantic", np.int32)
+        eng.step(d_depth, obs["agent_position_and_rotation"], obs["camera_position_and_rotation"],
+                 [goal_id], **kwargs)
+        found, status, n_upd = eng.results()
+        # the reference zeroes the sentinels in the caller's array (mapper.py:282-283)
+        depth[...] = d_depth[0].cpu().numpy()
+        self._host_cache = {}
+        self.last_status, self.last_n_updates = int(status[0]), int(n_upd[0])
+        if status[0] & 1:
+            raise IndexError("index out of bounds for the semantic map (cell index below -dim)")
+        lower = self.map_bounds[:3]
+        self.prev_pos_px = self.world2map(np.asarray(obs["agent_position_and_rotation"])[:3], lower)
+        is_found = True if found[0] else None
+        if is_found:
+            self.found_idx = self._disk_indices(self.prev_pos_px)
+        size = tuple(self.egomap_size)
+        blank = np.zeros((size[1], size[0], 3), dtype=np.uint8)
+        unc = np.full((size[1], size[0]), -0.5, dtype=np.float32) if self.probablistic_mapping else None
+        ego = (blank, blank.copy(), unc, None if unc is None else unc.copy())
+        return ego, is_found
+
+    def _disk_indices(self, center):
+        """Row/column index arrays of the found disk (mapper.py:737-743, 785)."""
+        radius = int(self.found_dist_m / self.pixel2meter)
+        rows, cols = _engine.map_size(self.map_bounds, self.pixel2meter)
+        hw = np.full(radius + 1, -1, dtype=np.int64)
+        err, dx, dy, plus, minus = 0, radius, 0, 1, 2 * radius - 1
+        while dx >= dy:
+            hw[dy] = max(hw[dy], dx)
+            hw[dx] = max(hw[dx], dy)
+            dy += 1
+            err += plus
+            plus += 2
+            if err > 0:
+                err -= minus
+                dx -= 1
+                minus -= 2
+        rr, cc = [], []
+        for k in range(-radius, radius + 1):
+            r = int(center[0]) + k
+            if r < 0 or r >= rows or hw[abs(k)] < 0:
+                continue
+            c0, c1 = max(int(center[1]) - hw[abs(k)], 0), min(int(center[1]) + hw[abs(k)], cols - 1)
+            if c0 <= c1:
+                rr.append(np.full(c1 - c0 + 1, r))
+                cc.append(np.arange(c0, c1 + 1))
+        if not rr:
+            return (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        return (np.concatenate(rr), np.concatenate(cc))
+
+    def world2map(self, world_coords_m: np.ndarray, world_lower_bound_m: np.ndarray) -> np.ndarray:
+        d = world_coords_m - world_lower_bound_m
+        uv = np.stack([d[..., 2], d[..., 0]], axis=-1)
+        return np.floor(uv / self.pixel2meter).astype(np.int64)
+
+    def map2world(self, map_coords: np.ndarray, world_lower_bound_m: np.ndarray) -> np.ndarray:
+        uv = np.stack([map_coords[..., 1], map_coords[..., 0]], axis=-1) * self.pixel2meter
+        return uv + world_lower_bound_m[[0, 2]]
+
+    def compute_fp_fn_detections(self, task_goal_ids, bboxes):
+        raise NotImplementedError("compute_fp_fn_detections is not built yet")
+
+    # ------------------------------------------------------------------ public map arrays
+    def _host(self, name):
+        if self._engine is None or not getattr(self, "_bound", False):
+            return None
+        maps = self._engine.maps[0]
+        if name not in maps:
+            return None
+        if name not in self._host_cache:
+            arr = maps[name].cpu().numpy()
+            if arr.dtype == np.int32:
+                arr = arr.view(np.uint32)
+            self._host_cache[name] = arr
+        return self._host_cache[name]
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: serve the map arrays from the device
+        if name in _MAP_NAMES:
+            val = self._host(name)
+            if val is None and name != "unc_map":
+                raise AttributeError(name)
+            return val
+        raise AttributeError(name)

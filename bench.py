@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Map-fusion throughput on MI355X: frames/s of the whole per-step fusion path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of stages 1-5 (softmax/entropy, back-projection, tallest-per-cell,
+rule update, found decision) over one batch of E frames per GPU, inputs resident in HBM.
+Default workload = BASELINE.json configs[1]: height_map_log_odds, 16 envs per GPU,
+640x480 frames, 40 classes, logits in (T = 3.2), 480x480 maps.  Environments are sharded by
+GPU with no collective in the inner loop (weak scaling); RCCL carries only the timing
+max and the final metric sum.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (prob_aggregate, C, T, map bounds, attrs)
+    "log_odds_c40": dict(rule="height_map_log_odds", C=40, T=3.2, span=14.39,
+                         attrs=dict(entropy_threshold=0.0171)),
+    "avg_prob_c40": dict(rule="height_map_avg_prob", C=40, T=3.2, span=14.39,
+                         attrs=dict(entropy_threshold=0.43759)),
+    "w2_avg_prob_c150": dict(rule="height_map_w2_avg_prob", C=150, T=2.5, span=14.39,
+                             attrs=dict(entropy_threshold=0.4820)),
+    "goal_decay_c40": dict(rule="height_map_goal_decay", C=40, T=3.2, span=14.39,
+                           filter_goal_prob=0.38158, attrs=dict(goal_decay=0.8931, goal_mark=1.5408)),
+    "prob_hv_c40": dict(rule="height_map_prob_hv", C=40, T=3.2, span=28.79,
+                        attrs=dict(hv_ratio=0.887, hv_min_views=5, hv_limit_obj_view_dist=4.13219)),
+}
+H, W = 480, 640
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def synth_frames(n_envs, n_classes, seed0, device):
+    """BASELINE frame recipe, one numpy generator per env (seed = global env index)."""
+    depth = np.empty((n_envs, H, W), np.float32)
+    gt = np.empty((n_envs, H, W), np.int32)
+    logits = torch.empty((n_envs, n_classes, H, W), dtype=torch.float32, device=device)
+    for e in range(n_envs):
+        rng = np.random.default_rng(seed0 + e)
+        d = rng.uniform(0.6, 4.9, (H, W)).astype(np.float32)
+        bad = rng.random((H, W)) < 0.02
+        which = rng.random((H, W)) < 0.5
+        d[bad & which] = np.float32(0.5)
+        d[bad & ~which] = np.float32(5.0)
+        depth[e] = d
+        gt[e] = rng.integers(0, 9, (H, W))
+        lg = (3.0 * rng.standard_normal((n_classes, H, W), dtype=np.float32)).astype(np.float32)
+        logits[e] = torch.from_numpy(lg).to(device)
+    return (torch.from_numpy(depth).to(device), logits, torch.from_numpy(gt).to(device))
+
+
+def make_poses(n_envs, center, rng):
+    from tests import scenes
+    ag, cam = [], []
+    for _ in range(n_envs):
+        a, c = scenes.make_pose(center, 0.0, center, rng.uniform(0.0, 2 * np.pi))
+        ag.append(a)
+        cam.append(c)
+    return np.stack(ag), np.stack(cam)
+
+
+def algorithmic_bytes_per_frame(n_classes, k_updates, prob_rule):
+    """Compulsory traffic: every input element once, every touched state element once."""
+    n = H * W
+    geometry = 4 * n + 2 * 56
+    stage1 = 4 * n_classes * n + 3 * 4 * n
+    if prob_rule:
+        state = 2 * 4 * k_updates * n_classes + 2 * 4 * k_updates * 4
+    else:
+        state = 2 * 4 * k_updates * 4
+    return geometry, stage1, state
+
+
+def cpu_baseline(workload, n_frames, seed):
+    """The CPU oracle (numpy port of the reference path) on the same workload, one core."""
+    from oracle import mapper_oracle as mo
+    from oracle import stage1_oracle as s1
+    from tests import scenes
+    torch.set_num_threads(1)
+    wl = WORKLOADS[workload]
+    lut = scenes.schema_lut(wl["C"])
+    m = mo.OracleMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                        probablistic_mapping=True, prob_aggregate=wl["rule"],
+                        seg_model_n_classes=wl["C"], filter_goal_prob=wl.get("filter_goal_prob"),
+                        schema_lut=lut)
+    for k, v in wl["attrs"].items():
+        setattr(m, k, v)
+    m.reset(np.array([0, 0, 0, wl["span"], 3.0, wl["span"]]))
+    rng = np.random.default_rng(seed)
+    fr = scenes.uniform_frame(rng, H, W, wl["C"], wl["T"], lut=lut, with_probs=False)
+    prng = np.random.default_rng(seed + 1)
+    elapsed, done = 0.0, 0
+    for i in range(n_frames + 1):
+        ag, cam = make_poses(1, wl["span"] / 2, prng)
+        depth = fr["depth"].copy()
+        t0 = time.perf_counter()
+        out = s1.predict_tail(fr["logits"], wl["T"], lut)
+        obs = {"depth": depth, "semantic_gt": fr["semantic_gt"], "objectgoal": np.array([0]),
+               "agent_position_and_rotation": ag[0], "camera_position_and_rotation": cam[0],
+               "semantic": out["semantic"], "semantic_prob": out["semantic_prob"],
+               "semantic_unc": out["semantic_unc"], "semantic_max_prob": out["semantic_max_prob"]}
+        m.update(obs)
+        dt = time.perf_counter() - t0
+        if i > 0:   # first frame is warm-up
+            elapsed += dt
+            done += 1
+        if elapsed > 25.0:
+            break
+    return done / elapsed, done
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="log_odds_c40", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=60)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import semantic_search_amd as ssa
+    from tests import scenes
+
+    wl = WORKLOADS[args.workload]
+    E, C = args.envs_per_gpu, wl["C"]
+    prob_rule = any(t in wl["rule"] for t in ("avg_prob", "log_odds"))
+    span = wl["span"]
+    map_hw = ssa.map_size([0, 0, 0, span, 3.0, span], 0.03)
+    eng = ssa.MapEngine(E, (H, W), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                        probablistic_mapping=True, prob_aggregate=wl["rule"], seg_model_n_classes=C,
+                        max_map_hw=map_hw, filter_goal_prob=wl.get("filter_goal_prob"), device=device)
+    for k, v in wl["attrs"].items():
+        setattr(eng.params, k, v)
+    eng.set_schema(scenes.schema_lut(C))
+    for e in range(E):
+        eng.reset_env(e, [0, 0, 0, span, 3.0, span])
+    depth, logits, gt = synth_frames(E, C, rank * E, device)
+    sem = torch.empty((E, H, W), dtype=torch.int32, device=device)
+    unc = torch.empty((E, H, W), dtype=torch.float32, device=device)
+    maxp = torch.empty((E, H, W), dtype=torch.float32, device=device)
+    goals = np.full(E, 3, dtype=np.int32)
+    prng = np.random.default_rng(1000 + rank)
+    total_steps = args.warmup + 2 * args.steps
+    poses = [make_poses(E, span / 2, prng) for _ in range(total_steps)]
+
+    def one_step(i):
+        ag, cam = poses[i]
+        eng.step(depth, ag, cam, goals, logits=logits, temperature=wl["T"], semantic=sem,
+                 semantic_unc=unc, semantic_max_prob=maxp, semantic_gt=gt)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    found, status, n_upd = eng.results()
+    assert not status.any(), "engine reported an index error on a benchmark frame"
+
+    # second pass of the same K steps with per-stage HIP events on the launch stream
+    eng.profile_begin(args.steps)
+    for i in range(args.steps):
+        one_step(args.warmup + args.steps + i)
+    stage_ms, n_prof = eng.profile_read()
+    found, status, n_upd = eng.results()
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    metric = torch.tensor([float(args.steps * E), float(found.sum()), float(n_upd.sum())],
+                          dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(metric, op=dist.ReduceOp.SUM)   # the path's only exchange: final metric sum
+    elapsed = float(t_max.item())
+    frames_total = float(metric[0].item())
+
+    if rank == 0:
+        k_mean = float(n_upd.mean())
+        geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, k_mean, prob_rule)
+        # dominant kernel = the streaming stage-1 (+ rule) pass, stage group [2]
+        dom_ms = stage_ms[2] / max(n_prof, 1)
+        dom_bytes = (s1_b + (state_b if prob_rule else 0)) * E
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        line = {
+            "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",
+            "value": frames_total / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{wl['rule']}, {E} envs per GPU, 640x480 frames, {C} classes, "
+                                   f"logits in (T={wl['T']}), {map_hw[0]}x{map_hw[1]} map",
+                       "envs_per_gpu": E, "frames_per_step": E * world,
+                       "mean_update_cells_per_frame": k_mean,
+                       "algorithmic_MB_per_frame": (geo_b + s1_b + state_b) / 1e6,
+                       "whole_path_frac_of_hbm_peak":
+                           (geo_b + s1_b + state_b) * (frames_total / world / elapsed) / 1e9 / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "kernel": "k_stream (stage 1 + rule update)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms},
+            "stage_ms_per_step": {"geometry": stage_ms[0] / max(n_prof, 1),
+                                  "winners": stage_ms[1] / max(n_prof, 1),
+                                  "stream_rule": stage_ms[2] / max(n_prof, 1),
+                                  "found": stage_ms[3] / max(n_prof, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0)
+            line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": f"{n_done} frames of the same workload (1 env, stage 1 on "
+                                              "torch CPU + numpy oracle), 1 thread"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,12 +153,21 @@ int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature,
 int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status,
                        int32_t *n_updates, void *stream);
 
-/* Device pointer to the last step's update list of env `e`: n_updates pairs
- * (flat pixel index, flat map cell index) as int32[2], unordered. */
+/* Device pointer to the last step's update list of env `e` (the reference's
+ * valid_flat_idx / update_cell_idx, mapper.py:333-337): n_updates int32 pairs, unordered.
+ * Word 0: flat pixel index in bits 0-28; bit 29 = dropped because a later pixel writes the
+ * same wrapped cell; bits 30 / 31 = the cell's row / column index was negative before numpy's
+ * wrap.  Word 1: flat index of the (wrapped) map cell. */
 int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev);
 
-/* Algorithmic bytes one ssmap_step moves per frame for the bound config (reads of every
- * input element once + state touched once, K = winners of the last read step). */
+/* Measurement hooks (no counterpart in the reference).  After ssmap_profile_begin the next
+ * `max_steps` calls of ssmap_step record HIP events on their stream around four stage
+ * groups: [0] header reset + geometry, [1] tallest-per-cell + wrap resolution,
+ * [2] stage 1 + rule update, [3] found decision.  ssmap_profile_read waits for `stream`,
+ * returns the summed milliseconds per group and the number of recorded steps, and rearms. */
+int ssmap_profile_begin(ssmap_engine *eng, int32_t max_steps);
+int ssmap_profile_read(ssmap_engine *eng, double *stage_ms, int32_t *n_steps, void *stream);
+
 const char *ssmap_last_error(void);
 const char *ssmap_version(void);
 

@@ -17,7 +17,7 @@ ENV_INDEX_ERROR = 1
 
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
            "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_stage1",
-           "ssmap_read_results", "ssmap_update_list", "ssmap_last_error", "ssmap_version")
+           "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read", "ssmap_last_error", "ssmap_version")
 
 
 class Config(C.Structure):
@@ -77,6 +77,8 @@ def load():
     lib.ssmap_stage1.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.ssmap_read_results.argtypes = [vp, vp, vp, vp, vp]
     lib.ssmap_update_list.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.ssmap_profile_begin.argtypes = [vp, i32]
+    lib.ssmap_profile_read.argtypes = [vp, vp, vp, vp]
     lib.ssmap_last_error.restype = C.c_char_p
     lib.ssmap_version.restype = C.c_char_p
     for name in EXPORTS:

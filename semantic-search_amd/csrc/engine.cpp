@@ -113,7 +113,12 @@ struct ssmap_engine {
     bool have_params = false, have_schema = false, have_palette = false;
     Quat flip_cam{};
     int device = 0;
+    // optional per-stage timing (ssmap_profile_begin / ssmap_profile_read)
+    std::vector<hipEvent_t> prof_events;   // kProfMarks per recorded step
+    int prof_capacity = 0, prof_steps = 0;
 };
+
+constexpr int kProfMarks = 5;   // 4 stage intervals
 
 extern "C" {
 
@@ -124,11 +129,12 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.winners);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.winners); hipFree(v.claim);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
     hipFree(eng->d_disk); hipFree(eng->d_palette);
+    for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
     for (int i = 0; i < kPoseRing; ++i) {
         if (eng->h_poses[i]) hipHostFree(eng->h_poses[i]);
         if (eng->pose_done[i]) hipEventDestroy(eng->pose_done[i]);
@@ -142,7 +148,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     const ssmap_config &c = *cfg;
     if (c.n_envs < 1 || c.img_h < 1 || c.img_w < 4 || (c.img_w % 4) != 0)
         return fail(SSMAP_ERR_INVALID_ARG, "n_envs >= 1, img_h >= 1 and img_w a positive multiple of 4 are required");
-    if ((int64_t)c.img_h * c.img_w >= (1 << 30))
+    if ((int64_t)c.img_h * c.img_w >= (1 << 29))
         return fail(SSMAP_ERR_INVALID_ARG, "frame too large");
     if (c.rule < SSMAP_RULE_DIRECT || c.rule > SSMAP_RULE_PROB_HV)
         return fail(SSMAP_ERR_INVALID_ARG, "Invalid prob_aggregate");
@@ -183,6 +189,9 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&v.horder, EN));
     if (prob_rule) TRY_ALLOC(dev_alloc(&v.target, EN));
     TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
+    v.claim_stride = (int64_t)c.max_map_h * c.max_map_w;
+    TRY_ALLOC(dev_alloc(&v.claim, (size_t)v.E * v.claim_stride));
+    hipMemset(v.claim, 0, sizeof(int32_t) * v.E * v.claim_stride);
     if (c.rule == SSMAP_RULE_GOAL_DECAY) {
         v.local_stride = 4ll * c.max_map_h * c.max_map_w;
         TRY_ALLOC(dev_alloc(&v.local_ids, (size_t)v.E * v.local_stride));
@@ -348,16 +357,27 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     HIP_TRY(hipMemcpyAsync(eng->d_poses, pb, sizeof(PoseBlock) * c.n_envs, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(eng->pose_done[slot], stream));
 
+    hipEvent_t *marks = nullptr;
+    if (eng->prof_capacity && eng->prof_steps < eng->prof_capacity)
+        marks = eng->prof_events.data() + (size_t)kProfMarks * eng->prof_steps++;
+#define MARK(i) do { if (marks) HIP_TRY(hipEventRecord(marks[i], stream)); } while (0)
+    MARK(0);
     launch_begin_step(v, stream);
     launch_geometry(v, *f, stream);
+    MARK(1);
     launch_winners(v, stream);
+    launch_resolve_wrapped(v, stream);
+    MARK(2);
     if (prob_rule) {
         launch_stream(v, *f, true, nullptr, stream);
     } else {
         if (f->logits) launch_stream(v, *f, false, nullptr, stream);
         launch_label_rules(v, *f, stream);
     }
+    MARK(3);
     launch_found(v, stream);
+    MARK(4);
+#undef MARK
     HIP_TRY(hipGetLastError());
     v.cur_overlay ^= 1;
     return SSMAP_OK;
@@ -390,6 +410,37 @@ int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status, int3
         if (status) status[e] = eng->h_hdr[e].status;
         if (n_updates) n_updates[e] = (int32_t)eng->h_hdr[e].n_winners;
     }
+    return SSMAP_OK;
+}
+
+int ssmap_profile_begin(ssmap_engine *eng, int32_t max_steps) {
+    if (!eng || max_steps < 0 || max_steps > 4096) return fail(SSMAP_ERR_INVALID_ARG, "bad step count");
+    for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
+    eng->prof_events.clear();
+    eng->prof_capacity = eng->prof_steps = 0;
+    for (int i = 0; i < max_steps * kProfMarks; ++i) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        eng->prof_events.push_back(ev);
+    }
+    eng->prof_capacity = max_steps;
+    return SSMAP_OK;
+}
+
+int ssmap_profile_read(ssmap_engine *eng, double *stage_ms, int32_t *n_steps, void *stream_v) {
+    if (!eng || !stage_ms || !n_steps) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream_v)));
+    for (int k = 0; k < kProfMarks - 1; ++k) stage_ms[k] = 0.0;
+    for (int s = 0; s < eng->prof_steps; ++s) {
+        const hipEvent_t *m = eng->prof_events.data() + (size_t)kProfMarks * s;
+        for (int k = 0; k < kProfMarks - 1; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, m[k], m[k + 1]));
+            stage_ms[k] += ms;
+        }
+    }
+    *n_steps = eng->prof_steps;
+    eng->prof_steps = 0;
     return SSMAP_OK;
 }
 

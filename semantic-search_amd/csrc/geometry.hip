@@ -24,7 +24,8 @@ __global__ void k_begin_step(View v) {
     h.found = 0;
     h.any_goal = 0;
     h.n_overlay = 0;
-    h.pad[0] = h.pad[1] = 0;
+    h.n_neg = 0;
+    h.pad = 0;
     v.hdr[e] = h;
     v.overlay_count[v.cur_overlay][e] = 0;
 }
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
             const int cell = wr * Wm + wc;
             const int pix = (int)(w >> 1);
+            if (row < 0 || col < 0) atomicAdd(&hdr->n_neg, 1u);
             if (write_target) v.target[fbase + pix] = cell;
             if (write_list) {
                 const unsigned pos = s_base + atomicAdd(&s_count, 1u);
@@ -280,6 +282,48 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
         atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
     }
     (void)s_box;
+}
+
+// numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
+// happens when an update cell with a negative index wraps onto another update cell
+// (mapper.py:326-338 masks only the upper bounds).  Frames with wrapped cells let the update
+// pixel with the highest flat index own the cell; the others are dropped.
+__global__ void k_claim_wrapped(View v) {
+    const int e = blockIdx.y;
+    const FrameHeader *hdr = v.hdr + e;
+    if (hdr->n_neg == 0) return;
+    const unsigned n = hdr->n_winners;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + (int64_t)e * v.N;
+    int32_t *claim = v.claim + e * v.claim_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 pc = list[i];
+        atomicMax(&claim[pc.y], (int)((uint32_t)pc.x & kPixMask) + 1);
+    }
+}
+
+__global__ void k_resolve_wrapped(View v, int write_target) {
+    const int e = blockIdx.y;
+    const FrameHeader *hdr = v.hdr + e;
+    if (hdr->n_neg == 0) return;
+    const unsigned n = hdr->n_winners;
+    const int64_t fbase = (int64_t)e * v.N;
+    int2 *list = reinterpret_cast<int2 *>(v.winners) + fbase;
+    const int32_t *claim = v.claim + e * v.claim_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 pc = list[i];
+        const int pix = (int)((uint32_t)pc.x & kPixMask);
+        if (claim[pc.y] != pix + 1) {
+            list[i].x = (int)((uint32_t)pc.x | kLostBit);
+            if (write_target) v.target[fbase + pix] = -1;
+        }
+    }
+}
+
+void launch_resolve_wrapped(const View &v, hipStream_t s) {
+    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
+    dim3 grid(32, v.E);
+    hipLaunchKernelGGL(k_claim_wrapped, grid, dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_resolve_wrapped, grid, dim3(256), 0, s, v, prob_rule ? 1 : 0);
 }
 
 void launch_begin_step(const View &v, hipStream_t s) {

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 pc = list[i];
         const uint32_t pw = (uint32_t)pc.x;
+        if (pw & kLostBit) continue;
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
         const float h = raise_height(v, mp, pb, fbase, pix, cell);
@@ -157,6 +158,7 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 pc = list[i];
         const uint32_t pw = (uint32_t)pc.x;
+        if (pw & kLostBit) continue;
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
         raise_height(v, mp, pb, fbase, pix, cell);
@@ -316,6 +318,13 @@ __global__ __launch_bounds__(256) void k_found(View v) {
         }
     }
     if (found) v.hdr[e].found = 1;
+    // release the wrapped-cell claims of this frame
+    if (v.hdr[e].n_neg) {
+        const unsigned n = v.hdr[e].n_winners;
+        const int2 *list = reinterpret_cast<const int2 *>(v.winners) + (int64_t)e * v.N;
+        int32_t *claim = v.claim + e * v.claim_stride;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) claim[list[i].y] = 0;
+    }
 }
 
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {

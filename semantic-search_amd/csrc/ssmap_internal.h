@@ -16,7 +16,8 @@ constexpr uint32_t kCoordMask = (1u << kCoordBits) - 1;
 constexpr uint32_t kUpdBit = 1u << 28;        // pixel passes height cut-off, depth and upper bounds
 constexpr uint32_t kRowNegBit = 1u << 30;     // update-list pixel word: the cell row was negative
 constexpr uint32_t kColNegBit = 1u << 31;     // ... the cell column was negative (numpy wrap)
-constexpr uint32_t kPixMask = (1u << 30) - 1;
+constexpr uint32_t kLostBit = 1u << 29;       // ... another update pixel owns the same wrapped cell
+constexpr uint32_t kPixMask = (1u << 29) - 1;
 constexpr int kSlots = 8192;                  // cells per LDS winner table
 constexpr int kSlotShift = 13;
 constexpr int kGeomPixPerBlock = 1024;        // geometry kernel: 256 threads x 4 pixels
@@ -45,7 +46,8 @@ struct FrameHeader {
     int32_t found;
     uint32_t any_goal;                    // goal_decay: some update pixel carries the goal id
     uint32_t n_overlay;                   // hv: goal overlays written this step
-    uint32_t pad[2];
+    uint32_t n_neg;                       // update cells reached through a negative (wrapped) index
+    uint32_t pad;
 };
 
 struct EnvState {
@@ -67,6 +69,8 @@ struct View {
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
     int32_t *target;           // [E][N] flat map cell this pixel updates, or -1
     int32_t *winners;          // [E][N][2] (pixel, cell) pairs, unordered
+    int32_t *claim;            // [E][maxHm*maxWm] 1 + highest update pixel per wrapped cell (0 = none)
+    int64_t claim_stride;
     uint8_t *local_ids;        // goal_decay: [E][4*maxHm*maxWm] id+1 on the update bbox
     uint8_t *local_eroded;     // goal_decay: same shape
     int32_t *overlay[2];       // hv: [E][N] cells showing the goal overlay (prev / current)
@@ -96,6 +100,7 @@ __host__ __device__ inline double unorder_f64(unsigned long long k) {
 void launch_begin_step(const View &v, hipStream_t s);
 void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_winners(const View &v, hipStream_t s);
+void launch_resolve_wrapped(const View &v, hipStream_t s);
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_found(const View &v, hipStream_t s);

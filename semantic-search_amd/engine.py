@@ -292,6 +292,18 @@ class MapEngine:
                                                     n_upd.ctypes.data, C.c_void_p(stream)))
         return found.astype(bool), status, n_upd
 
+    def profile_begin(self, max_steps: int):
+        _capi.check(self.lib.ssmap_profile_begin(self._h, int(max_steps)))
+
+    def profile_read(self):
+        """(ms per stage group summed over the recorded steps [4], number of steps)."""
+        ms = np.zeros(4, dtype=np.float64)
+        n = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _capi.check(self.lib.ssmap_profile_read(self._h, ms.ctypes.data, C.byref(n), C.c_void_p(stream)))
+        return ms, int(n.value)
+
     def update_list(self, e: int, n_updates: int):
         """(pixels, cells) of env e's last step as host int arrays sorted by pixel index."""
         p = C.c_void_p()
@@ -304,8 +316,10 @@ class MapEngine:
         holder = _RawDeviceBuffer(p.value, n_updates * 8, self.device)
         buf.view(torch.uint8).reshape(-1).copy_(holder.tensor())
         host = buf.cpu().numpy().astype(np.int64)
-        pix = host[:, 0] & ((1 << 30) - 1)
+        keep = (host[:, 0] & (1 << 29)) == 0     # dropped: another pixel owns the wrapped cell
+        pix = host[:, 0] & ((1 << 29) - 1)
         order = np.argsort(pix, kind="stable")
+        self.last_list_dropped = int((~keep).sum())
         return pix[order], host[order, 1]
 
 

@@ -239,6 +239,10 @@ int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n, const int
         HIP_TRY(hipMemcpy(eng->d_pool_ids, pool_ids, 6 * SSMAP_MAX_POOL * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(eng->d_pool_count, pool_count, 6 * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    eng->view.pool_trivial = 1;
+    if (pool_ids && pool_count)
+        for (int g = 0; g < 6; ++g)
+            if (pool_count[g] > 1) eng->view.pool_trivial = 0;
     eng->have_schema = true;
     return SSMAP_OK;
 }

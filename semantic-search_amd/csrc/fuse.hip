@@ -2,10 +2,12 @@
 // stage 4 for the probability rules (avg_prob / w_avg_prob / w2_avg_prob, mapper.py:517-569;
 // log_odds, mapper.py:570-603): ONE pass over the class-major [C][H][W] tensor.
 //
-// Each thread owns one pixel and keeps its C values in a private LDS column (stride 257
-// floats: conflict-free both when a thread walks its column and when a wave reads one
-// column across classes).  Pixels that won a map cell (target[pix] >= 0, written by the
-// winner kernel) are then handed to whole waves: lanes run over the classes, so the
+// Each thread owns one pixel.  Its C values are loaded with C independent coalesced loads
+// (lane <-> pixel, so one wave-load reads 256 contiguous bytes of one class plane) and kept
+//   * in registers when C is one of the compiled sizes (kernel k_stream_reg), or
+//   * in a private LDS column of stride 257 floats otherwise (kernel k_stream_lds).
+// Pixels that won a map cell (target[pix] >= 0, written by the winner kernel) then hand their
+// probability vector to a whole wave through LDS: lanes run over the classes, so the
 // read-modify-write of the cell's C contiguous floats in the fused map is coalesced and the
 // per-cell entropy / argmax are wavefront reductions.
 #include "ssmap_internal.h"
@@ -14,6 +16,8 @@ namespace ssmap {
 
 constexpr int kTile = 256;
 constexpr int kStride = kTile + 1;
+constexpr int kChunk = 32;       // winners staged per round in the register kernel
+constexpr int kMaxPerLane = 3;   // classes per lane in the winner phase: C <= 192
 
 __device__ inline float wave_sum(float x) {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -57,15 +61,209 @@ __device__ inline void commit_cell(const ssmap_env_maps &mp, const uint8_t *pale
     dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
 }
 
-constexpr int kMaxPerLane = 3;   // classes per lane: C <= 192 (the LDS tile caps C below that)
+struct StreamArgs {
+    const float *in;
+    int from_logits;
+    float inv_t;
+    int pool_trivial;        // every goal id pools at most one class: confidence = max prob
+    int32_t *sem_out;
+    float *unc_out, *maxp_out, *probs_out;
+    const int32_t *gt;
+};
 
-// MODE 0: stage 1 only.  MODE 1: avg family.  MODE 2: log-odds.
+// One update cell, processed by a whole wave.  `pvec` points at the winner pixel's C
+// probabilities in LDS with element stride `pstride`.  MODE 1: avg family, MODE 2: log-odds.
 template <int MODE>
-__global__ __launch_bounds__(kTile) void k_stream(View v, const float *__restrict__ in, int from_logits,
-                                                  float inv_t, int32_t *__restrict__ sem_out,
-                                                  float *__restrict__ unc_out, float *__restrict__ maxp_out,
-                                                  float *__restrict__ probs_out,
-                                                  const int32_t *__restrict__ gt) {
+__device__ inline void update_cell(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
+                                   const float *pvec, int pstride, int cell, int64_t gpix,
+                                   const int32_t *gt, int lane, float log_c) {
+    const int C = v.C;
+    float *mrow = mp.prob_map + (int64_t)cell * C;
+    // height map and ground-truth map (mapper.py:338-341, 361-363); lane 0 stores
+    const double hw = unorder_f64(v.horder[gpix]);
+    const float hnew = fmaxf(mp.height_map[cell], (float)(hw - pb.agent[1]));
+
+    float p[kMaxPerLane], mv[kMaxPerLane];
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        p[j] = c < C ? pvec[c * pstride] : 0.0f;
+        mv[j] = c < C ? mrow[c] : 0.0f;
+    }
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    if (MODE == 1) {
+        float wgt = 1.0f;
+        if (v.rule != SSMAP_RULE_AVG_PROB) {
+            float sp = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxPerLane; ++j) sp += p[j];
+            sp = wave_sum(sp);
+            float hs = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxPerLane; ++j) hs += (lane + 64 * j < C) ? entr(p[j] / sp) : 0.0f;
+            const float ent = wave_sum(hs) / log_c;
+            wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
+        }
+        const float wn = mp.weight_map[cell] + wgt;
+        const float rcp = 1.0f / wn;
+        float sm = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                const float d = rcp * (p[j] - mv[j]);
+                mv[j] = mv[j] + d * wgt;
+                mrow[c] = mv[j];
+                sm += mv[j];
+            }
+        }
+        sm = wave_sum(sm);
+        float hs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                hs += entr(mv[j] / sm);
+                if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
+            }
+        }
+        const float ent = wave_sum(hs) / log_c;
+        if (lane == 0) {
+            mp.weight_map[cell] = wn;
+            mp.unc_map[cell] = ent;
+        }
+    } else {
+        const float p0 = pvec[0];
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                mv[j] = mv[j] + __logf(p[j] / p0);
+                mrow[c] = mv[j];
+                if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
+            }
+        }
+    }
+    wave_argmax(best, bi);
+    if (lane == 0) {
+        mp.height_map[cell] = hnew;
+        if (gt) mp.gt_map[cell] = (uint32_t)gt[gpix];
+        const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
+        commit_cell(mp, v.palette, cell, id);
+    }
+}
+
+// Ranks the winner pixels of a 256-pixel tile; returns the tile's winner count.
+__device__ inline int rank_winners(bool win, int tgt, int *s_wave_cnt, int *s_win_t, int *s_win_cell, int &rank) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long ball = __ballot(win);
+    if (lane == 0) s_wave_cnt[wave] = __popcll(ball);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += s_wave_cnt[w];
+        total += s_wave_cnt[w];
+    }
+    rank = -1;
+    if (win) {
+        rank = before + __popcll(ball & ((1ull << lane) - 1ull));
+        s_win_t[rank] = t;
+        s_win_cell[rank] = tgt;
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------- register kernel
+template <int CT, int MODE>
+__global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
+    __shared__ float stage[MODE == 0 ? 1 : kChunk * (CT + 1)];
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_win_t[MODE == 0 ? 1 : kTile];
+    __shared__ int s_win_cell[MODE == 0 ? 1 : kTile];
+
+    const int e = blockIdx.y;
+    const int t = threadIdx.x;
+    const int pix = blockIdx.x * kTile + t;
+    const bool active = pix < v.N;
+    const int64_t fbase = (int64_t)e * v.N;
+    const float *src = a.in + ((int64_t)e * CT) * v.N + (active ? pix : 0);
+
+    float x[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) x[c] = src[(int64_t)c * v.N];
+
+    if (a.from_logits) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { x[c] *= a.inv_t; m = fmaxf(m, x[c]); }
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { x[c] = __expf(x[c] - m); s += x[c]; }
+        const float inv_s = 1.0f / s;
+        float hsum = 0.0f, best = -1.0f;
+        int bi = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            x[c] *= inv_s;
+            hsum += x[c] * __logf(x[c] + 1e-6f);
+            if (x[c] > best) { best = x[c]; bi = c; }
+        }
+        const int sid = v.lut[bi];
+        float conf = best;
+        if (!a.pool_trivial && sid >= 3 && sid <= 8) {
+            // probability mass of every model class mapped to this goal id (infer.py:109-118)
+            float acc = 0.0f;
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const bool hit = v.lut[c] == sid;
+                acc += hit ? x[c] : 0.0f;
+                any |= hit;
+            }
+            if (any) conf = acc;
+        }
+        if (active) {
+            if (a.sem_out) a.sem_out[fbase + pix] = sid;
+            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / __logf((float)CT);
+            if (a.maxp_out) a.maxp_out[fbase + pix] = conf;
+            if (a.probs_out) {
+                float *dst = a.probs_out + ((int64_t)e * CT) * v.N + pix;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) dst[(int64_t)c * v.N] = x[c];
+            }
+        }
+    }
+    if (MODE == 0) return;
+
+    const int tgt = active ? v.target[fbase + pix] : -1;
+    const bool win = tgt >= 0;
+    int rank;
+    const int total = rank_winners(win, tgt, s_wave_cnt, s_win_t, s_win_cell, rank);
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const float log_c = logf((float)CT);
+    const int lane = t & 63, wave = t >> 6;
+
+    for (int base = 0; base < total; base += kChunk) {
+        if (win && rank >= base && rank < base + kChunk) {
+            float *dst = stage + (rank - base) * (CT + 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) dst[c] = x[c];
+        }
+        __syncthreads();
+        const int n_here = min(kChunk, total - base);
+        for (int w = wave; w < n_here; w += 4) {
+            const int64_t gpix = fbase + blockIdx.x * kTile + s_win_t[base + w];
+            update_cell<MODE>(v, mp, pb, stage + w * (CT + 1), 1, s_win_cell[base + w], gpix, a.gt, lane, log_c);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- generic (LDS column) kernel
+template <int MODE>
+__global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
     extern __shared__ float tile[];   // [C][kStride]
     __shared__ int s_wave_cnt[4];
     __shared__ int s_win_t[kTile];
@@ -77,18 +275,22 @@ __global__ __launch_bounds__(kTile) void k_stream(View v, const float *__restric
     const bool active = pix < v.N;
     const int C = v.C;
     const int64_t fbase = (int64_t)e * v.N;
-    const float *src = in + ((int64_t)e * C) * v.N + pix;
+    const float *src = a.in + ((int64_t)e * C) * v.N + (active ? pix : 0);
     float *col = tile + t;
 
-    if (active) {
-        for (int c = 0; c < C; ++c) col[c * kStride] = src[(int64_t)c * v.N];
+    for (int c0 = 0; c0 < C; c0 += 8) {   // 8 loads in flight per thread
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = (c0 + j < C) ? src[(int64_t)(c0 + j) * v.N] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (c0 + j < C) col[(c0 + j) * kStride] = tmp[j];
     }
-    if (from_logits && active) {
+    if (a.from_logits) {
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) {
-            const float x = col[c * kStride] * inv_t;
-            col[c * kStride] = x;
-            m = fmaxf(m, x);
+            const float xv = col[c * kStride] * a.inv_t;
+            col[c * kStride] = xv;
+            m = fmaxf(m, xv);
         }
         float s = 0.0f;
         for (int c = 0; c < C; ++c) {
@@ -108,146 +310,75 @@ __global__ __launch_bounds__(kTile) void k_stream(View v, const float *__restric
         const int sid = v.lut[bi];
         float conf = best;
         if (sid >= 3 && sid <= 8) {
-            // probability mass of every model class that maps to this goal id (infer.py:109-118)
             const int g = sid - 3;
             const int n = v.pool_count[g];
             float acc = 0.0f;
             for (int k = 0; k < n; ++k) acc += col[v.pool_ids[g * SSMAP_MAX_POOL + k] * kStride];
             if (n > 0) conf = acc;
         }
-        if (sem_out) sem_out[fbase + pix] = sid;
-        if (unc_out) unc_out[fbase + pix] = -hsum / __logf((float)C);
-        if (maxp_out) maxp_out[fbase + pix] = conf;
-        if (probs_out) {
-            float *dst = probs_out + ((int64_t)e * C) * v.N + pix;
-            for (int c = 0; c < C; ++c) dst[(int64_t)c * v.N] = col[c * kStride];
+        if (active) {
+            if (a.sem_out) a.sem_out[fbase + pix] = sid;
+            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / __logf((float)C);
+            if (a.maxp_out) a.maxp_out[fbase + pix] = conf;
+            if (a.probs_out) {
+                float *dst = a.probs_out + ((int64_t)e * C) * v.N + pix;
+                for (int c = 0; c < C; ++c) dst[(int64_t)c * v.N] = col[c * kStride];
+            }
         }
     }
     if (MODE == 0) return;
 
-    // ---- hand the winner pixels of this tile to the waves
     const int tgt = active ? v.target[fbase + pix] : -1;
     const bool win = tgt >= 0;
-    const unsigned long long ball = __ballot(win);
-    const int lane = t & 63, wave = t >> 6;
-    if (lane == 0) s_wave_cnt[wave] = __popcll(ball);
+    int rank;
+    const int total = rank_winners(win, tgt, s_wave_cnt, s_win_t, s_win_cell, rank);
     __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) before += s_wave_cnt[w];
-        total += s_wave_cnt[w];
-    }
-    if (win) {
-        const int rank = before + __popcll(ball & ((1ull << lane) - 1ull));
-        s_win_t[rank] = t;
-        s_win_cell[rank] = tgt;
-    }
-    __syncthreads();
-
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
-    const float log_c_np = logf((float)C);
-
+    const float log_c = logf((float)C);
+    const int lane = t & 63, wave = t >> 6;
     for (int w = wave; w < total; w += 4) {
         const int tw = s_win_t[w];
-        const int cell = s_win_cell[w];
-        const int wpix = blockIdx.x * kTile + tw;
-        float *mrow = mp.prob_map + (int64_t)cell * C;
-
-        // height map and ground-truth map (mapper.py:338-341, 361-363); every lane computes,
-        // lane 0 stores
-        const double hw = unorder_f64(v.horder[fbase + wpix]);
-        const float hnew = fmaxf(mp.height_map[cell], (float)(hw - pb.agent[1]));
-
-        float p[kMaxPerLane], mv[kMaxPerLane];
-#pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
-            const int c = lane + 64 * j;
-            p[j] = c < C ? tile[c * kStride + tw] : 0.0f;
-            mv[j] = c < C ? mrow[c] : 0.0f;
-        }
-        float best = -INFINITY;
-        int bi = 0x7FFFFFFF;
-
-        if (MODE == 1) {
-            float wgt = 1.0f;
-            if (v.rule != SSMAP_RULE_AVG_PROB) {
-                float sp = 0.0f;
-#pragma unroll
-                for (int j = 0; j < kMaxPerLane; ++j) sp += p[j];
-                sp = wave_sum(sp);
-                float hs = 0.0f;
-#pragma unroll
-                for (int j = 0; j < kMaxPerLane; ++j) hs += (lane + 64 * j < C) ? entr(p[j] / sp) : 0.0f;
-                const float ent = wave_sum(hs) / log_c_np;
-                wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
-            }
-            const float wn = mp.weight_map[cell] + wgt;
-            const float rcp = 1.0f / wn;
-            float sm = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    const float d = rcp * (p[j] - mv[j]);
-                    mv[j] = mv[j] + d * wgt;
-                    mrow[c] = mv[j];
-                    sm += mv[j];
-                }
-            }
-            sm = wave_sum(sm);
-            float hs = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    hs += entr(mv[j] / sm);
-                    if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
-                }
-            }
-            const float ent = wave_sum(hs) / log_c_np;
-            if (lane == 0) {
-                mp.weight_map[cell] = wn;
-                mp.unc_map[cell] = ent;
-            }
-        } else {
-            const float p0 = tile[tw];
-#pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    mv[j] = mv[j] + __logf(p[j] / p0);
-                    mrow[c] = mv[j];
-                    if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
-                }
-            }
-        }
-        wave_argmax(best, bi);
-        if (lane == 0) {
-            mp.height_map[cell] = hnew;
-            if (gt) mp.gt_map[cell] = (uint32_t)gt[fbase + wpix];
-            const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
-            commit_cell(mp, v.palette, cell, id);
-        }
+        const int64_t gpix = fbase + blockIdx.x * kTile + tw;
+        update_cell<MODE>(v, mp, pb, tile + tw, kStride, s_win_cell[w], gpix, a.gt, lane, log_c);
     }
 }
 
+template <int CT>
+static void launch_reg(int mode, dim3 grid, hipStream_t s, const View &v, const StreamArgs &a) {
+    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kTile), 0, s, v, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kTile), 0, s, v, a);
+    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kTile), 0, s, v, a);
+}
+
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s) {
-    const float *in = f.logits ? f.logits : f.probs;
-    const int from_logits = f.logits ? 1 : 0;
-    const float inv_t = 1.0f / f.temperature;
+    StreamArgs a;
+    a.in = f.logits ? f.logits : f.probs;
+    a.from_logits = f.logits ? 1 : 0;
+    a.inv_t = f.logits ? 1.0f / f.temperature : 1.0f;
+    a.pool_trivial = v.pool_trivial;
+    a.sem_out = f.semantic;
+    a.unc_out = f.semantic_unc;
+    a.maxp_out = f.semantic_max_prob;
+    a.probs_out = probs_out;
+    a.gt = f.semantic_gt;
     dim3 grid((v.N + kTile - 1) / kTile, v.E);
-    const size_t lds = (size_t)v.C * kStride * sizeof(float);
     int mode = 0;
     if (fuse) mode = v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1;
+    switch (v.C) {
+        case 37: launch_reg<37>(mode, grid, s, v, a); return;
+        case 40: launch_reg<40>(mode, grid, s, v, a); return;
+        case 150: launch_reg<150>(mode, grid, s, v, a); return;
+        default: break;
+    }
+    const size_t lds = (size_t)v.C * kStride * sizeof(float);
     auto go = [&](auto kern) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(kTile), lds, s, v, in, from_logits, inv_t, f.semantic,
-                           f.semantic_unc, f.semantic_max_prob, probs_out, f.semantic_gt);
+        hipLaunchKernelGGL(kern, grid, dim3(kTile), lds, s, v, a);
     };
-    if (mode == 0) go(k_stream<0>);
-    else if (mode == 1) go(k_stream<1>);
-    else go(k_stream<2>);
+    if (mode == 0) go(k_stream_lds<0>);
+    else if (mode == 1) go(k_stream_lds<1>);
+    else go(k_stream_lds<2>);
 }
 
 }  // namespace ssmap

@@ -250,10 +250,26 @@ __global__ void k_gd_apply(View v, int dil) {
 }
 
 // ---------------------------------------------------------------- stage 5
-// One block per env sweeps the filled disk of radius r around the robot cell (the disk is
-// given by per-row half widths, the raster of OpenCV's filled circle, mapper.py:737-743).
+// The filled disk of radius r around the robot cell (per-row half widths = the raster of
+// OpenCV's filled circle, mapper.py:737-743) is swept 64 cells at a time by each wave.  The
+// cheap per-cell tests run one cell per lane; for the probability rules the entropy of each
+// surviving goal cell is then computed by the whole wave, lanes over classes.
+constexpr int kFoundBlocks = 8;
+
+__device__ inline float wsum(float x) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ inline float wmaxf(float x) {
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ inline float entr_f(float x) {
+    return x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
+}
+
 __global__ __launch_bounds__(256) void k_found(View v) {
-    const int e = blockIdx.x;
+    const int e = blockIdx.y;
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
     const int goal = pb.goal_id;
@@ -261,65 +277,76 @@ __global__ __launch_bounds__(256) void k_found(View v) {
     const int C = v.C;
     const bool hv = v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV;
     const bool avg = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_W2_AVG_PROB;
+    const bool by_entropy = avg || v.rule == SSMAP_RULE_LOG_ODDS;
     const float log_c = C > 0 ? logf((float)C) : 1.0f;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int n_chunks = (side * side + 63) >> 6;
     bool found = false;
-    for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
-        const int dr = i / side - R, dc = i % side - R;
-        const int half = v.disk_hw[dr < 0 ? -dr : dr];
-        if (half < 0 || dc < -half || dc > half) continue;
-        const int row = pb.robot_row + dr, col = pb.robot_col + dc;
-        if (row < 0 || row >= mp.map_h || col < 0 || col >= mp.map_w) continue;
-        const int cell = row * mp.map_w + col;
+    for (int chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int i = chunk * 64 + lane;
+        int cell = -1;
+        if (i < side * side) {
+            const int dr = i / side - R, dc = i % side - R;
+            const int half = v.disk_hw[dr < 0 ? -dr : dr];
+            const int row = pb.robot_row + dr, col = pb.robot_col + dc;
+            if (half >= 0 && dc >= -half && dc <= half && row >= 0 && row < mp.map_h && col >= 0 && col < mp.map_w)
+                cell = row * mp.map_w + col;
+        }
         if (hv) {
+            if (cell < 0) continue;
             const float views = mp.views[cell], hits = mp.hits[cell];
-            if (!(views > v.prm.hv_min_views && hits > 0.0f)) continue;
-            if (views == INFINITY) continue;
+            if (!(views > v.prm.hv_min_views && hits > 0.0f) || views == INFINITY) continue;
             if (hits / views > v.prm.hv_ratio) {
                 found = true;
             } else {   // rejected for good (mapper.py:763-772)
                 mp.views[cell] = INFINITY;
                 const int bg = (int)mp.background_map[cell];
                 mp.semantic_map[cell] = (uint32_t)bg;
-                const uint8_t *rgb = v.palette + 3 * bg;
-                uint8_t *dst = mp.semantic_map_color + 3ll * cell;
-                dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+                paint(mp, v.palette, cell, bg);
             }
             continue;
         }
-        if ((int)mp.semantic_map[cell] != goal) continue;
-        if (avg || v.rule == SSMAP_RULE_LOG_ODDS) {
-            const float *m = mp.prob_map + (int64_t)cell * C;
+        const bool cand = cell >= 0 && (int)mp.semantic_map[cell] == goal;
+        if (!by_entropy) {
+            found |= cand;
+            continue;
+        }
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int gcell = __shfl(cell, src);
+            const float *m = mp.prob_map + (int64_t)gcell * C;
             float ent;
             if (avg) {
                 float s = 0.0f;
-                for (int c = 0; c < C; ++c) s += m[c];
+                for (int c = lane; c < C; c += 64) s += m[c];
+                s = wsum(s);
                 float hs = 0.0f;
-                for (int c = 0; c < C; ++c) {
-                    const float x = m[c] / s;
-                    hs += x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
-                }
-                ent = hs / log_c;
+                for (int c = lane; c < C; c += 64) hs += entr_f(m[c] / s);
+                ent = wsum(hs) / log_c;
             } else {   // softmax of the log-odds first (mapper.py:805-812)
                 float mx = -INFINITY;
-                for (int c = 0; c < C; ++c) mx = fmaxf(mx, m[c]);
+                for (int c = lane; c < C; c += 64) mx = fmaxf(mx, m[c]);
+                mx = wmaxf(mx);
                 float s = 0.0f;
-                for (int c = 0; c < C; ++c) s += expf(m[c] - mx);
-                float s2 = 0.0f, hs = 0.0f;
-                for (int c = 0; c < C; ++c) s2 += expf(m[c] - mx) / s;
-                for (int c = 0; c < C; ++c) {
-                    const float x = (expf(m[c] - mx) / s) / s2;
-                    hs += x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
-                }
-                ent = hs / log_c;
+                for (int c = lane; c < C; c += 64) s += expf(m[c] - mx);
+                s = wsum(s);
+                float s2 = 0.0f;
+                for (int c = lane; c < C; c += 64) s2 += expf(m[c] - mx) / s;
+                s2 = wsum(s2);
+                float hs = 0.0f;
+                for (int c = lane; c < C; c += 64) hs += entr_f((expf(m[c] - mx) / s) / s2);
+                ent = wsum(hs) / log_c;
             }
             if (ent < v.prm.entropy_threshold) found = true;
-        } else {
-            found = true;
         }
     }
     if (found) v.hdr[e].found = 1;
     // release the wrapped-cell claims of this frame
-    if (v.hdr[e].n_neg) {
+    if (blockIdx.x == 0 && v.hdr[e].n_neg) {
         const unsigned n = v.hdr[e].n_winners;
         const int2 *list = reinterpret_cast<const int2 *>(v.winners) + (int64_t)e * v.N;
         int32_t *claim = v.claim + e * v.claim_stride;
@@ -343,7 +370,7 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
 }
 
 void launch_found(const View &v, hipStream_t s) {
-    hipLaunchKernelGGL(k_found, dim3(v.E), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_found, dim3(kFoundBlocks, v.E), dim3(256), 0, s, v);
 }
 
 }  // namespace ssmap

@@ -80,6 +80,7 @@ struct View {
     const int32_t *lut;        // [C] model class -> schema id
     const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
     const int32_t *pool_count; // [6]
+    int32_t pool_trivial;      // no goal id pools more than one class
     const uint8_t *palette;    // [n][3]
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;

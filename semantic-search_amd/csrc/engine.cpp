@@ -129,7 +129,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.winners); hipFree(v.claim);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -187,11 +187,14 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
     TRY_ALLOC(dev_alloc(&v.cellid, EN));
     TRY_ALLOC(dev_alloc(&v.horder, EN));
-    if (prob_rule) TRY_ALLOC(dev_alloc(&v.target, EN));
+    if (prob_rule) {
+        TRY_ALLOC(dev_alloc(&v.target, EN));
+        TRY_ALLOC(dev_alloc(&v.wprob, EN * (size_t)v.C));
+    }
     TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
-    v.claim_stride = (int64_t)c.max_map_h * c.max_map_w;
-    TRY_ALLOC(dev_alloc(&v.claim, (size_t)v.E * v.claim_stride));
-    hipMemset(v.claim, 0, sizeof(int32_t) * v.E * v.claim_stride);
+    v.quad_stride = 4ll * c.max_map_h * c.max_map_w;
+    TRY_ALLOC(dev_alloc(&v.quad, (size_t)v.E * v.quad_stride));
+    hipMemset(v.quad, 0, sizeof(int32_t) * v.E * v.quad_stride);
     if (c.rule == SSMAP_RULE_GOAL_DECAY) {
         v.local_stride = 4ll * c.max_map_h * c.max_map_w;
         TRY_ALLOC(dev_alloc(&v.local_ids, (size_t)v.E * v.local_stride));
@@ -374,6 +377,7 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     MARK(2);
     if (prob_rule) {
         launch_stream(v, *f, true, nullptr, stream);
+        launch_update_prob(v, *f, stream);
     } else {
         if (f->logits) launch_stream(v, *f, false, nullptr, stream);
         launch_label_rules(v, *f, stream);

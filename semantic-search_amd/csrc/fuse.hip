@@ -6,17 +6,17 @@
 // (lane <-> pixel, so one wave-load reads 256 contiguous bytes of one class plane) and kept
 //   * in registers when C is one of the compiled sizes (kernel k_stream_reg), or
 //   * in a private LDS column of stride 257 floats otherwise (kernel k_stream_lds).
-// Pixels that won a map cell (target[pix] >= 0, written by the winner kernel) then hand their
-// probability vector to a whole wave through LDS: lanes run over the classes, so the
-// read-modify-write of the cell's C contiguous floats in the fused map is coalesced and the
-// per-cell entropy / argmax are wavefront reductions.
+// Pixels that won a map cell (target[pix] = their slot in the frame's update list, written by
+// the winner kernel) copy their probability vector to row `slot` of a compact [K][C] buffer;
+// the streaming pass never waits on map memory.  k_update_prob then gives every update cell
+// to a wave, lanes over the classes: the read-modify-write of the cell's C contiguous floats
+// in the fused map is coalesced and the per-cell entropy / argmax are wavefront reductions.
 #include "ssmap_internal.h"
 
 namespace ssmap {
 
 constexpr int kTile = 256;
 constexpr int kStride = kTile + 1;
-constexpr int kChunk = 32;       // winners staged per round in the register kernel
 constexpr int kMaxPerLane = 3;   // classes per lane in the winner phase: C <= 192
 
 __device__ inline float wave_sum(float x) {
@@ -71,117 +71,109 @@ struct StreamArgs {
     const int32_t *gt;
 };
 
-// One update cell, processed by a whole wave.  `pvec` points at the winner pixel's C
-// probabilities in LDS with element stride `pstride`.  MODE 1: avg family, MODE 2: log-odds.
-template <int MODE>
-__device__ inline void update_cell(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
-                                   const float *pvec, int pstride, int cell, int64_t gpix,
-                                   const int32_t *gt, int lane, float log_c) {
+// Up to NB update cells processed by one wave, lanes over classes.  All global loads of the
+// batch (fused-map rows, weights, heights) are issued before any of them is consumed, so a
+// wave pays one memory round trip per batch instead of one per cell.  `pvec(j)` is the LDS
+// address of cell j's probability vector (element stride `pstride`); live[j] = process it.
+// MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
+template <int MODE, int PL, int NB>
+__device__ inline void update_cells(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
+                                    const float *const *pvec, int pstride, const int *cells,
+                                    const int64_t *gpix, const bool *live, const int32_t *gt, int lane,
+                                    float log_c) {
     const int C = v.C;
-    float *mrow = mp.prob_map + (int64_t)cell * C;
-    // height map and ground-truth map (mapper.py:338-341, 361-363); lane 0 stores
-    const double hw = unorder_f64(v.horder[gpix]);
-    const float hnew = fmaxf(mp.height_map[cell], (float)(hw - pb.agent[1]));
-
-    float p[kMaxPerLane], mv[kMaxPerLane];
+    float p[NB][PL], mv[NB][PL], h_old[NB], w_old[NB];
+    unsigned long long hk[NB];
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        p[j] = c < C ? pvec[c * pstride] : 0.0f;
-        mv[j] = c < C ? mrow[c] : 0.0f;
+    for (int b = 0; b < NB; ++b) {
+        if (live[b]) {
+            const float *mrow = mp.prob_map + (int64_t)cells[b] * C;
+#pragma unroll
+            for (int j = 0; j < PL; ++j) {
+                const int c = lane + 64 * j;
+                mv[b][j] = c < C ? mrow[c] : 0.0f;
+                p[b][j] = c < C ? pvec[b][c * pstride] : 0.0f;
+            }
+            h_old[b] = mp.height_map[cells[b]];
+            hk[b] = v.horder[gpix[b]];
+            w_old[b] = MODE == 1 ? mp.weight_map[cells[b]] : 0.0f;
+        }
     }
-    float best = -INFINITY;
-    int bi = 0x7FFFFFFF;
-    if (MODE == 1) {
-        float wgt = 1.0f;
-        if (v.rule != SSMAP_RULE_AVG_PROB) {
-            float sp = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) sp += p[j];
-            sp = wave_sum(sp);
+    for (int b = 0; b < NB; ++b) {
+        if (!live[b]) continue;
+        const int cell = cells[b];
+        float *mrow = mp.prob_map + (int64_t)cell * C;
+        // height map (mapper.py:338-341)
+        const float hnew = fmaxf(h_old[b], (float)(unorder_f64(hk[b]) - pb.agent[1]));
+        float best = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        if (MODE == 1) {
+            float wgt = 1.0f;
+            if (v.rule != SSMAP_RULE_AVG_PROB) {
+                float sp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PL; ++j) sp += p[b][j];
+                sp = wave_sum(sp);
+                float hs = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PL; ++j) hs += (lane + 64 * j < C) ? entr(p[b][j] / sp) : 0.0f;
+                const float ent = wave_sum(hs) / log_c;
+                wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
+            }
+            const float wn = w_old[b] + wgt;
+            const float rcp = 1.0f / wn;
+            float sm = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < C) {
+                    const float d = rcp * (p[b][j] - mv[b][j]);
+                    mv[b][j] = mv[b][j] + d * wgt;
+                    mrow[c] = mv[b][j];
+                    sm += mv[b][j];
+                }
+            }
+            sm = wave_sum(sm);
             float hs = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) hs += (lane + 64 * j < C) ? entr(p[j] / sp) : 0.0f;
+            for (int j = 0; j < PL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < C) {
+                    hs += entr(mv[b][j] / sm);
+                    if (arg_better(mv[b][j], c, best, bi)) { best = mv[b][j]; bi = c; }
+                }
+            }
             const float ent = wave_sum(hs) / log_c;
-            wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
-        }
-        const float wn = mp.weight_map[cell] + wgt;
-        const float rcp = 1.0f / wn;
-        float sm = 0.0f;
+            if (lane == 0) {
+                mp.weight_map[cell] = wn;
+                mp.unc_map[cell] = ent;
+            }
+        } else {
+            const float p0 = pvec[b][0];
 #pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
-            const int c = lane + 64 * j;
-            if (c < C) {
-                const float d = rcp * (p[j] - mv[j]);
-                mv[j] = mv[j] + d * wgt;
-                mrow[c] = mv[j];
-                sm += mv[j];
+            for (int j = 0; j < PL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < C) {
+                    mv[b][j] = mv[b][j] + __logf(p[b][j] / p0);
+                    mrow[c] = mv[b][j];
+                    if (arg_better(mv[b][j], c, best, bi)) { best = mv[b][j]; bi = c; }
+                }
             }
         }
-        sm = wave_sum(sm);
-        float hs = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
-            const int c = lane + 64 * j;
-            if (c < C) {
-                hs += entr(mv[j] / sm);
-                if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
-            }
-        }
-        const float ent = wave_sum(hs) / log_c;
+        wave_argmax(best, bi);
         if (lane == 0) {
-            mp.weight_map[cell] = wn;
-            mp.unc_map[cell] = ent;
-        }
-    } else {
-        const float p0 = pvec[0];
-#pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
-            const int c = lane + 64 * j;
-            if (c < C) {
-                mv[j] = mv[j] + __logf(p[j] / p0);
-                mrow[c] = mv[j];
-                if (arg_better(mv[j], c, best, bi)) { best = mv[j]; bi = c; }
-            }
+            mp.height_map[cell] = hnew;
+            if (gt) mp.gt_map[cell] = (uint32_t)gt[gpix[b]];
+            const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
+            commit_cell(mp, v.palette, cell, id);
         }
     }
-    wave_argmax(best, bi);
-    if (lane == 0) {
-        mp.height_map[cell] = hnew;
-        if (gt) mp.gt_map[cell] = (uint32_t)gt[gpix];
-        const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
-        commit_cell(mp, v.palette, cell, id);
-    }
-}
-
-// Ranks the winner pixels of a 256-pixel tile; returns the tile's winner count.
-__device__ inline int rank_winners(bool win, int tgt, int *s_wave_cnt, int *s_win_t, int *s_win_cell, int &rank) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned long long ball = __ballot(win);
-    if (lane == 0) s_wave_cnt[wave] = __popcll(ball);
-    __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) before += s_wave_cnt[w];
-        total += s_wave_cnt[w];
-    }
-    rank = -1;
-    if (win) {
-        rank = before + __popcll(ball & ((1ull << lane) - 1ull));
-        s_win_t[rank] = t;
-        s_win_cell[rank] = tgt;
-    }
-    return total;
 }
 
 // ---------------------------------------------------------------- register kernel
 template <int CT, int MODE>
 __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
-    __shared__ float stage[MODE == 0 ? 1 : kChunk * (CT + 1)];
-    __shared__ int s_wave_cnt[4];
-    __shared__ int s_win_t[MODE == 0 ? 1 : kTile];
-    __shared__ int s_win_cell[MODE == 0 ? 1 : kTile];
-
     const int e = blockIdx.y;
     const int t = threadIdx.x;
     const int pix = blockIdx.x * kTile + t;
@@ -235,29 +227,11 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
         }
     }
     if (MODE == 0) return;
-
-    const int tgt = active ? v.target[fbase + pix] : -1;
-    const bool win = tgt >= 0;
-    int rank;
-    const int total = rank_winners(win, tgt, s_wave_cnt, s_win_t, s_win_cell, rank);
-    const ssmap_env_maps &mp = v.envs[e].maps;
-    const PoseBlock &pb = v.poses[e];
-    const float log_c = logf((float)CT);
-    const int lane = t & 63, wave = t >> 6;
-
-    for (int base = 0; base < total; base += kChunk) {
-        if (win && rank >= base && rank < base + kChunk) {
-            float *dst = stage + (rank - base) * (CT + 1);
+    const int slot = active ? v.target[fbase + pix] : -1;
+    if (slot >= 0) {
+        float *dst = v.wprob + (fbase + slot) * CT;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) dst[c] = x[c];
-        }
-        __syncthreads();
-        const int n_here = min(kChunk, total - base);
-        for (int w = wave; w < n_here; w += 4) {
-            const int64_t gpix = fbase + blockIdx.x * kTile + s_win_t[base + w];
-            update_cell<MODE>(v, mp, pb, stage + w * (CT + 1), 1, s_win_cell[base + w], gpix, a.gt, lane, log_c);
-        }
-        __syncthreads();
+        for (int c = 0; c < CT; ++c) dst[c] = x[c];
     }
 }
 
@@ -265,9 +239,6 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
     extern __shared__ float tile[];   // [C][kStride]
-    __shared__ int s_wave_cnt[4];
-    __shared__ int s_win_t[kTile];
-    __shared__ int s_win_cell[kTile];
 
     const int e = blockIdx.y;
     const int t = threadIdx.x;
@@ -327,20 +298,43 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
         }
     }
     if (MODE == 0) return;
+    const int slot = active ? v.target[fbase + pix] : -1;
+    if (slot >= 0) {
+        float *dst = v.wprob + (fbase + slot) * C;
+        for (int c = 0; c < C; ++c) dst[c] = col[c * kStride];
+    }
+}
 
-    const int tgt = active ? v.target[fbase + pix] : -1;
-    const bool win = tgt >= 0;
-    int rank;
-    const int total = rank_winners(win, tgt, s_wave_cnt, s_win_t, s_win_cell, rank);
-    __syncthreads();
+// ---------------------------------------------------------------- rule update
+// One wave per batch of NB update cells (list slots), lanes over classes.
+template <int MODE, int PL>
+__global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__restrict__ gt) {
+    constexpr int NB = 4;
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    const unsigned n = v.hdr[e].n_winners;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
-    const float log_c = logf((float)C);
-    const int lane = t & 63, wave = t >> 6;
-    for (int w = wave; w < total; w += 4) {
-        const int tw = s_win_t[w];
-        const int64_t gpix = fbase + blockIdx.x * kTile + tw;
-        update_cell<MODE>(v, mp, pb, tile + tw, kStride, s_win_cell[w], gpix, a.gt, lane, log_c);
+    const float log_c = logf((float)v.C);
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned i0 = gw * NB; i0 < n; i0 += n_waves * NB) {
+        const float *pv[NB];
+        int cells[NB];
+        int64_t gp[NB];
+        bool live[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const unsigned i = i0 + b;
+            const int2 pc = i < n ? list[i] : make_int2((int)kLostBit, 0);
+            live[b] = !((uint32_t)pc.x & kLostBit);
+            cells[b] = pc.y;
+            gp[b] = fbase + (int)((uint32_t)pc.x & kPixMask);
+            pv[b] = v.wprob + (fbase + i) * v.C;
+        }
+        update_cells<MODE, PL, NB>(v, mp, pb, pv, 1, cells, gp, live, gt, lane, log_c);
     }
 }
 
@@ -349,6 +343,17 @@ static void launch_reg(int mode, dim3 grid, hipStream_t s, const View &v, const 
     if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kTile), 0, s, v, a);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kTile), 0, s, v, a);
     else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kTile), 0, s, v, a);
+}
+
+void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
+    dim3 grid(256, v.E), block(256);
+    const bool lo = v.rule == SSMAP_RULE_LOG_ODDS;
+    const int pl = (v.C + 63) / 64;
+#define GO(MODE, PL) hipLaunchKernelGGL((k_update_prob<MODE, PL>), grid, block, 0, s, v, f.semantic_gt)
+    if (pl == 1) { if (lo) GO(2, 1); else GO(1, 1); }
+    else if (pl == 2) { if (lo) GO(2, 2); else GO(1, 2); }
+    else { if (lo) GO(2, 3); else GO(1, 3); }
+#undef GO
 }
 
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s) {

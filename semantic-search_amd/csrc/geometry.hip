@@ -263,9 +263,9 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             const int cell = wr * Wm + wc;
             const int pix = (int)(w >> 1);
             if (row < 0 || col < 0) atomicAdd(&hdr->n_neg, 1u);
-            if (write_target) v.target[fbase + pix] = cell;
             if (write_list) {
                 const unsigned pos = s_base + atomicAdd(&s_count, 1u);
+                if (write_target) v.target[fbase + pix] = (int)pos;
                 int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
                 const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
                 *out = make_int2((int)word, cell);
@@ -286,33 +286,31 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
 // happens when an update cell with a negative index wraps onto another update cell
-// (mapper.py:326-338 masks only the upper bounds).  Frames with wrapped cells let the update
-// pixel with the highest flat index own the cell; the others are dropped.
-__global__ void k_claim_wrapped(View v) {
-    const int e = blockIdx.y;
-    const FrameHeader *hdr = v.hdr + e;
-    if (hdr->n_neg == 0) return;
-    const unsigned n = hdr->n_winners;
-    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + (int64_t)e * v.N;
-    int32_t *claim = v.claim + e * v.claim_stride;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int2 pc = list[i];
-        atomicMax(&claim[pc.y], (int)((uint32_t)pc.x & kPixMask) + 1);
-    }
-}
-
-__global__ void k_resolve_wrapped(View v, int write_target) {
-    const int e = blockIdx.y;
+// (mapper.py:326-338 masks only the upper bounds).  At most four update pixels can reach one
+// wrapped cell -- one per sign quadrant of (row, col) -- so frames with wrapped cells record
+// each update pixel in its quadrant slot of the cell; the highest pixel index owns the cell
+// and the others are flagged.  One block per env: slots are written, then compared.
+__global__ __launch_bounds__(1024) void k_resolve_wrapped(View v, int write_target) {
+    const int e = blockIdx.x;
     const FrameHeader *hdr = v.hdr + e;
     if (hdr->n_neg == 0) return;
     const unsigned n = hdr->n_winners;
     const int64_t fbase = (int64_t)e * v.N;
     int2 *list = reinterpret_cast<int2 *>(v.winners) + fbase;
-    const int32_t *claim = v.claim + e * v.claim_stride;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int32_t *quad = v.quad + e * v.quad_stride;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const int2 pc = list[i];
+        const uint32_t pw = (uint32_t)pc.x;
+        const int q = ((pw & kRowNegBit) ? 2 : 0) | ((pw & kColNegBit) ? 1 : 0);
+        quad[4ll * pc.y + q] = (int)(pw & kPixMask) + 1;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
         const int2 pc = list[i];
         const int pix = (int)((uint32_t)pc.x & kPixMask);
-        if (claim[pc.y] != pix + 1) {
+        const int4 qs = *reinterpret_cast<const int4 *>(quad + 4ll * pc.y);
+        const int owner = max(max(qs.x, qs.y), max(qs.z, qs.w));
+        if (owner != pix + 1) {
             list[i].x = (int)((uint32_t)pc.x | kLostBit);
             if (write_target) v.target[fbase + pix] = -1;
         }
@@ -321,9 +319,7 @@ __global__ void k_resolve_wrapped(View v, int write_target) {
 
 void launch_resolve_wrapped(const View &v, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
-    dim3 grid(32, v.E);
-    hipLaunchKernelGGL(k_claim_wrapped, grid, dim3(256), 0, s, v);
-    hipLaunchKernelGGL(k_resolve_wrapped, grid, dim3(256), 0, s, v, prob_rule ? 1 : 0);
+    hipLaunchKernelGGL(k_resolve_wrapped, dim3(v.E), dim3(1024), 0, s, v, prob_rule ? 1 : 0);
 }
 
 void launch_begin_step(const View &v, hipStream_t s) {

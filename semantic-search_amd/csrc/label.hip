@@ -11,6 +11,7 @@
 namespace ssmap {
 
 constexpr int kListBlocks = 64;      // blocks per env for list / bbox sweeps
+constexpr int kGdLost = 0x80;        // goal_decay local map: pixel lost its wrapped cell to a later one
 
 __device__ inline int occupancy_override(int id, float h, int use_height, int n_schema) {
     if (!use_height || n_schema != 9) return id;
@@ -158,17 +159,20 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 pc = list[i];
         const uint32_t pw = (uint32_t)pc.x;
-        if (pw & kLostBit) continue;
+        const bool lost = (pw & kLostBit) != 0;   // a later pixel writes the same wrapped cell
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
-        raise_height(v, mp, pb, fbase, pix, cell);
-        mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
+        if (!lost) {
+            raise_height(v, mp, pb, fbase, pix, cell);
+            mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
+        }
         int id = semantic[fbase + pix];
         if (v.prm.use_filter && id == goal && (1.0f - unc[fbase + pix]) < v.prm.filter_goal_prob) id = 0;
         int row = cell / mp.map_w, col = cell - row * mp.map_w;
         if (pw & kRowNegBit) row -= mp.map_h;
         if (pw & kColNegBit) col -= mp.map_w;
-        local[(int64_t)(row - r0) * bw + (col - c0)] = (uint8_t)(id + 1);
+        // the local map is indexed by UNWRAPPED cells, so wrapped twins stay distinct here
+        local[(int64_t)(row - r0) * bw + (col - c0)] = (uint8_t)((id + 1) | (lost ? kGdLost : 0));
         if (id == goal) hdr->any_goal = 1u;
     }
 }
@@ -193,11 +197,29 @@ __global__ void k_gd_erode(View v, int size) {
             for (int dc = -a; dc < size - a; ++dc) {
                 const int cc = c + dc;
                 if (cc < 0 || cc >= bw) continue;
-                if (local[(int64_t)rr * bw + cc] != goal1) { keep = false; break; }
+                if ((local[(int64_t)rr * bw + cc] & (kGdLost - 1)) != goal1) { keep = false; break; }
             }
         }
         er[i] = keep ? 1 : 0;
     }
+}
+
+// Is local cell (r, c) part of the rewritten update set (mapper.py:1157), and with which id?
+__device__ inline bool gd_member(const uint8_t *local, const uint8_t *er, int bh, int bw, int r, int c,
+                                 int lo, int hi, int goal, int &id) {
+    const int stored = local[(int64_t)r * bw + c] & (kGdLost - 1);
+    id = stored ? stored - 1 : 0;
+    if (id != goal && id != 0) return true;
+    for (int dr = -lo; dr <= hi; ++dr) {
+        const int rr = r + dr;
+        if (rr < 0 || rr >= bh) continue;
+        for (int dc = -lo; dc <= hi; ++dc) {
+            const int cc = c + dc;
+            if (cc < 0 || cc >= bw) continue;
+            if (er[(int64_t)rr * bw + cc]) return true;
+        }
+    }
+    return false;
 }
 
 __global__ void k_gd_apply(View v, int dil) {
@@ -211,37 +233,52 @@ __global__ void k_gd_apply(View v, int dil) {
     const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
     const uint8_t *er = v.local_eroded + (int64_t)e * v.local_stride;
     const int lo = (dil - 1) / 2, hi = (dil - 1) - lo;
+    const int Hm = mp.map_h, Wm = mp.map_w;
+    const bool may_wrap = r0 < 0 || c0 < 0;
     const int64_t n = (int64_t)bh * bw;
     for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / bw), c = (int)(i - (int64_t)r * bw);
-        const int stored = local[i];
-        int id = stored ? stored - 1 : 0;
-        bool valid;
+        int id;
+        bool has_goal, has_other;
         if (any_goal) {
-            bool grown = false;
-            for (int dr = -lo; dr <= hi && !grown; ++dr) {
-                const int rr = r + dr;
-                if (rr < 0 || rr >= bh) continue;
-                for (int dc = -lo; dc <= hi; ++dc) {
-                    const int cc = c + dc;
-                    if (cc < 0 || cc >= bw) continue;
-                    if (er[(int64_t)rr * bw + cc]) { grown = true; break; }
+            if (!gd_member(local, er, bh, bw, r, c, lo, hi, goal, id)) continue;
+            has_goal = id == goal;
+            has_other = !has_goal;
+            if (may_wrap) {
+                // Twins: members whose unwrapped index differs by the map size land on the same
+                // map cell.  numpy applies "+= 1" once if any twin is a goal cell, then
+                // "*= decay" once if any twin is not, and the semantic id of the LAST twin in
+                // row-major order of the local map (mapper.py:391-396, 730).
+                const int R = r + r0, Cc = c + c0;
+                bool last = true;
+                for (int k = 1; k < 4; ++k) {
+                    const int tr = (k & 2) ? (R < 0 ? R + Hm : R - Hm) : R;
+                    const int tc = (k & 1) ? (Cc < 0 ? Cc + Wm : Cc - Wm) : Cc;
+                    const int lr = tr - r0, lc = tc - c0;
+                    if (lr < 0 || lr >= bh || lc < 0 || lc >= bw) continue;
+                    int tid;
+                    if (!gd_member(local, er, bh, bw, lr, lc, lo, hi, goal, tid)) continue;
+                    if (tid == goal) has_goal = true; else has_other = true;
+                    if (tr > R || (tr == R && tc > Cc)) last = false;
                 }
+                if (!last) continue;
             }
-            valid = grown || (id != goal && id != 0);
         } else {
-            valid = stored != 0;
+            const int stored = local[i];
+            if (stored == 0 || (stored & kGdLost)) continue;   // only the last pixel of a wrapped cell writes
+            id = stored - 1;
+            has_goal = false;
+            has_other = true;
         }
-        if (!valid) continue;
         int row = r + r0, col = c + c0;
-        if (row < 0) row += mp.map_h;
-        if (col < 0) col += mp.map_w;
-        const int cell = row * mp.map_w + col;
-        const bool is_goal = id == goal;
+        if (row < 0) row += Hm;
+        if (col < 0) col += Wm;
+        const int cell = row * Wm + col;
         float g = mp.goal_map[cell];
-        g = is_goal ? g + 1.0f : g * v.prm.goal_decay;
+        if (has_goal) g = g + 1.0f;
+        if (has_other) g = g * v.prm.goal_decay;
         mp.goal_map[cell] = g;
-        if (is_goal) id = 0;
+        if (id == goal) id = 0;
         if (g > v.prm.goal_mark) id = goal;
         id = occupancy_override(id, mp.height_map[cell], v.use_height, v.n_schema);
         mp.semantic_map[cell] = (uint32_t)id;
@@ -345,12 +382,13 @@ __global__ __launch_bounds__(256) void k_found(View v) {
         }
     }
     if (found) v.hdr[e].found = 1;
-    // release the wrapped-cell claims of this frame
+    // clear the wrapped-cell quadrant slots of this frame
     if (blockIdx.x == 0 && v.hdr[e].n_neg) {
         const unsigned n = v.hdr[e].n_winners;
         const int2 *list = reinterpret_cast<const int2 *>(v.winners) + (int64_t)e * v.N;
-        int32_t *claim = v.claim + e * v.claim_stride;
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) claim[list[i].y] = 0;
+        int32_t *quad = v.quad + e * v.quad_stride;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+            *reinterpret_cast<int4 *>(quad + 4ll * list[i].y) = make_int4(0, 0, 0, 0);
     }
 }
 

@@ -67,10 +67,12 @@ struct View {
     FrameHeader *hdr;
     uint32_t *cellid;          // [E][N]
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
-    int32_t *target;           // [E][N] flat map cell this pixel updates, or -1
+    int32_t *target;           // [E][N] slot of this pixel in the frame's update list, or -1
+    float *wprob;              // [E][N][C] class probabilities of the update pixels, row = list slot
     int32_t *winners;          // [E][N][2] (pixel, cell) pairs, unordered
-    int32_t *claim;            // [E][maxHm*maxWm] 1 + highest update pixel per wrapped cell (0 = none)
-    int64_t claim_stride;
+    int32_t *quad;             // [E][maxHm*maxWm][4] 1 + update pixel of each index-sign quadrant that
+                               // lands on the wrapped cell (0 = none); non-zero only inside a step
+    int64_t quad_stride;       // ints per env
     uint8_t *local_ids;        // goal_decay: [E][4*maxHm*maxWm] id+1 on the update bbox
     uint8_t *local_eroded;     // goal_decay: same shape
     int32_t *overlay[2];       // hv: [E][N] cells showing the goal overlay (prev / current)
@@ -103,6 +105,7 @@ void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_winners(const View &v, hipStream_t s);
 void launch_resolve_wrapped(const View &v, hipStream_t s);
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);
+void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_found(const View &v, hipStream_t s);
 

@@ -129,7 +129,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.quad);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -192,6 +192,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
         TRY_ALLOC(dev_alloc(&v.wprob, EN * (size_t)v.C));
     }
     TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
+    TRY_ALLOC(dev_alloc(&v.wheight, EN));
     v.quad_stride = 4ll * c.max_map_h * c.max_map_w;
     TRY_ALLOC(dev_alloc(&v.quad, (size_t)v.E * v.quad_stride));
     hipMemset(v.quad, 0, sizeof(int32_t) * v.E * v.quad_stride);
@@ -221,6 +222,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.envs = eng->d_envs; v.poses = eng->d_poses; v.hdr = eng->d_hdr;
     v.lut = eng->d_lut; v.pool_ids = eng->d_pool_ids; v.pool_count = eng->d_pool_count;
     v.cur_overlay = 0;
+    if (const char *d = getenv("SSMAP_DEBUG")) v.dbg = atoi(d);
     *out = eng;
     return SSMAP_OK;
 }

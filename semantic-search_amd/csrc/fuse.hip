@@ -17,12 +17,6 @@ namespace ssmap {
 
 constexpr int kTile = 256;
 constexpr int kStride = kTile + 1;
-constexpr int kMaxPerLane = 3;   // classes per lane in the winner phase: C <= 192
-
-__device__ inline float wave_sum(float x) {
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
 
 // numpy argmax order: NaN beats everything, ties go to the lower index
 __device__ inline bool arg_better(float a, int ia, float b, int ib) {
@@ -31,14 +25,6 @@ __device__ inline bool arg_better(float a, int ia, float b, int ib) {
     if (an) return ia < ib;
     return a > b || (a == b && ia < ib);
 }
-__device__ inline void wave_argmax(float &val, int &idx) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(val, o);
-        const int oi = __shfl_xor(idx, o);
-        if (arg_better(ov, oi, val, idx)) { val = ov; idx = oi; }
-    }
-}
-
 // scipy.special.entr: -x log x, 0 at 0, -inf below 0
 __device__ inline float entr(float x) {
     if (x > 0.0f) return -x * __logf(x);
@@ -71,104 +57,29 @@ struct StreamArgs {
     const int32_t *gt;
 };
 
-// Up to NB update cells processed by one wave, lanes over classes.  All global loads of the
-// batch (fused-map rows, weights, heights) are issued before any of them is consumed, so a
-// wave pays one memory round trip per batch instead of one per cell.  `pvec(j)` is the LDS
-// address of cell j's probability vector (element stride `pstride`); live[j] = process it.
-// MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
-template <int MODE, int PL, int NB>
-__device__ inline void update_cells(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
-                                    const float *const *pvec, int pstride, const int *cells,
-                                    const int64_t *gpix, const bool *live, const int32_t *gt, int lane,
-                                    float log_c) {
-    const int C = v.C;
-    float p[NB][PL], mv[NB][PL], h_old[NB], w_old[NB];
-    unsigned long long hk[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        if (live[b]) {
-            const float *mrow = mp.prob_map + (int64_t)cells[b] * C;
-#pragma unroll
-            for (int j = 0; j < PL; ++j) {
-                const int c = lane + 64 * j;
-                mv[b][j] = c < C ? mrow[c] : 0.0f;
-                p[b][j] = c < C ? pvec[b][c * pstride] : 0.0f;
-            }
-            h_old[b] = mp.height_map[cells[b]];
-            hk[b] = v.horder[gpix[b]];
-            w_old[b] = MODE == 1 ? mp.weight_map[cells[b]] : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        if (!live[b]) continue;
-        const int cell = cells[b];
-        float *mrow = mp.prob_map + (int64_t)cell * C;
-        // height map (mapper.py:338-341)
-        const float hnew = fmaxf(h_old[b], (float)(unorder_f64(hk[b]) - pb.agent[1]));
-        float best = -INFINITY;
-        int bi = 0x7FFFFFFF;
-        if (MODE == 1) {
-            float wgt = 1.0f;
-            if (v.rule != SSMAP_RULE_AVG_PROB) {
-                float sp = 0.0f;
-#pragma unroll
-                for (int j = 0; j < PL; ++j) sp += p[b][j];
-                sp = wave_sum(sp);
-                float hs = 0.0f;
-#pragma unroll
-                for (int j = 0; j < PL; ++j) hs += (lane + 64 * j < C) ? entr(p[b][j] / sp) : 0.0f;
-                const float ent = wave_sum(hs) / log_c;
-                wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
-            }
-            const float wn = w_old[b] + wgt;
-            const float rcp = 1.0f / wn;
-            float sm = 0.0f;
-#pragma unroll
-            for (int j = 0; j < PL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    const float d = rcp * (p[b][j] - mv[b][j]);
-                    mv[b][j] = mv[b][j] + d * wgt;
-                    mrow[c] = mv[b][j];
-                    sm += mv[b][j];
-                }
-            }
-            sm = wave_sum(sm);
-            float hs = 0.0f;
-#pragma unroll
-            for (int j = 0; j < PL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    hs += entr(mv[b][j] / sm);
-                    if (arg_better(mv[b][j], c, best, bi)) { best = mv[b][j]; bi = c; }
-                }
-            }
-            const float ent = wave_sum(hs) / log_c;
-            if (lane == 0) {
-                mp.weight_map[cell] = wn;
-                mp.unc_map[cell] = ent;
-            }
-        } else {
-            const float p0 = pvec[b][0];
-#pragma unroll
-            for (int j = 0; j < PL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < C) {
-                    mv[b][j] = mv[b][j] + __logf(p[b][j] / p0);
-                    mrow[c] = mv[b][j];
-                    if (arg_better(mv[b][j], c, best, bi)) { best = mv[b][j]; bi = c; }
-                }
-            }
-        }
-        wave_argmax(best, bi);
-        if (lane == 0) {
-            mp.height_map[cell] = hnew;
-            if (gt) mp.gt_map[cell] = (uint32_t)gt[gpix[b]];
-            const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
-            commit_cell(mp, v.palette, cell, id);
-        }
-    }
+// ---- 16-lane row reductions with DPP rotates (no LDS traffic): after the four steps every
+// lane of a row holds the reduction over the row.
+template <int N>
+__device__ inline float row_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xF, 0xF, false));
+}
+template <int N>
+__device__ inline int row_ror(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
+}
+__device__ inline float row_sum(float x) {
+    x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); x += row_ror<1>(x);
+    return x;
+}
+template <int N>
+__device__ inline void row_argmax_step(float &val, int &idx) {
+    const float ov = row_ror<N>(val);
+    const int oi = row_ror<N>(idx);
+    if (arg_better(ov, oi, val, idx)) { val = ov; idx = oi; }
+}
+__device__ inline void row_argmax(float &val, int &idx) {
+    row_argmax_step<8>(val, idx); row_argmax_step<4>(val, idx);
+    row_argmax_step<2>(val, idx); row_argmax_step<1>(val, idx);
 }
 
 // ---------------------------------------------------------------- register kernel
@@ -306,35 +217,125 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
 }
 
 // ---------------------------------------------------------------- rule update
-// One wave per batch of NB update cells (list slots), lanes over classes.
-template <int MODE, int PL>
+// Stage 4 for the probability rules.  A wave works on four update cells at a time, one per
+// 16-lane row; lane `sub` of a row owns classes sub, sub+16, ... (CPL per lane), so every
+// load / store of a cell's C contiguous floats is 64 contiguous bytes per row and the
+// per-cell sums and argmax are 16-lane DPP reductions.  List slots are in row-major cell
+// order, so the four rows of a wave (and the waves of a block) touch neighbouring cells.
+// MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
+template <int MODE, int CPL>
 __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__restrict__ gt) {
-    constexpr int NB = 4;
+    constexpr int NB = 2;                       // row-batches in flight per wave
+    constexpr unsigned kRun = 4 * 4 * NB * 2;   // list slots per block pass
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
     const unsigned n = v.hdr[e].n_winners;
     const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
     const ssmap_env_maps &mp = v.envs[e].maps;
-    const PoseBlock &pb = v.poses[e];
-    const float log_c = logf((float)v.C);
-    const int lane = threadIdx.x & 63;
-    const unsigned gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-    for (unsigned i0 = gw * NB; i0 < n; i0 += n_waves * NB) {
-        const float *pv[NB];
-        int cells[NB];
-        int64_t gp[NB];
+    const double agent_y = v.poses[e].agent[1];
+    const int C = v.C;
+    const float log_c = logf((float)C);
+    const int lane = threadIdx.x & 63, sub = lane & 15, row = lane >> 4;
+    const unsigned wave = threadIdx.x >> 6;
+    for (unsigned r0 = blockIdx.x * kRun; r0 < n; r0 += gridDim.x * kRun)
+    for (unsigned i0 = r0 + wave * 4 * NB; i0 < min(n, r0 + kRun); i0 += 16 * NB) {
+        float p[NB][CPL], mv[NB][CPL], h_old[NB], w_old[NB], p_first[NB];
+        unsigned long long hk[NB];
+        int cell[NB], gtv[NB];
         bool live[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const unsigned i = i0 + b;
+            const unsigned i = i0 + 4 * b + row;
             const int2 pc = i < n ? list[i] : make_int2((int)kLostBit, 0);
             live[b] = !((uint32_t)pc.x & kLostBit);
-            cells[b] = pc.y;
-            gp[b] = fbase + (int)((uint32_t)pc.x & kPixMask);
-            pv[b] = v.wprob + (fbase + i) * v.C;
+            cell[b] = pc.y;
+            if (live[b]) {
+                const float *mrow = mp.prob_map + (int64_t)cell[b] * C;
+                const float *prow = v.wprob + (fbase + i) * C;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = sub + 16 * k;
+                    mv[b][k] = c < C ? mrow[c] : 0.0f;
+                    p[b][k] = c < C ? prow[c] : 0.0f;
+                }
+                h_old[b] = mp.height_map[cell[b]];
+                hk[b] = v.wheight[fbase + i];
+                w_old[b] = MODE == 1 ? mp.weight_map[cell[b]] : 0.0f;
+                p_first[b] = MODE == 2 ? prow[0] : 0.0f;
+                gtv[b] = gt ? gt[fbase + (int)((uint32_t)pc.x & kPixMask)] : 0;
+            }
         }
-        update_cells<MODE, PL, NB>(v, mp, pb, pv, 1, cells, gp, live, gt, lane, log_c);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // rows without a live cell still take part in the (row-local) DPP steps
+            float *mrow = mp.prob_map + (int64_t)cell[b] * C;
+            const bool on = live[b];
+            float best = -INFINITY;
+            int bi = 0x7FFFFFFF;
+            float ent_out = 0.0f, wn = 0.0f;
+            if (MODE == 1) {
+                float wgt = 1.0f;
+                if (v.rule != SSMAP_RULE_AVG_PROB) {
+                    float sp = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) sp += on ? p[b][k] : 0.0f;
+                    sp = row_sum(sp);
+                    float hs = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) hs += (on && sub + 16 * k < C) ? entr(p[b][k] / sp) : 0.0f;
+                    const float ent = row_sum(hs) / log_c;
+                    wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
+                }
+                wn = w_old[b] + wgt;
+                const float rcp = 1.0f / wn;
+                float sm = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = sub + 16 * k;
+                    if (on && c < C) {
+                        const float d = rcp * (p[b][k] - mv[b][k]);
+                        mv[b][k] = mv[b][k] + d * wgt;
+                        mrow[c] = mv[b][k];
+                        sm += mv[b][k];
+                    }
+                }
+                sm = row_sum(sm);
+                float hs = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = sub + 16 * k;
+                    if (on && c < C) {
+                        hs += entr(mv[b][k] / sm);
+                        if (arg_better(mv[b][k], c, best, bi)) { best = mv[b][k]; bi = c; }
+                    }
+                }
+                ent_out = row_sum(hs) / log_c;
+            } else {
+                const float p0 = p_first[b];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = sub + 16 * k;
+                    if (on && c < C) {
+                        mv[b][k] = mv[b][k] + __logf(p[b][k] / p0);
+                        mrow[c] = mv[b][k];
+                        if (arg_better(mv[b][k], c, best, bi)) { best = mv[b][k]; bi = c; }
+                    }
+                }
+            }
+            row_argmax(best, bi);
+            if (on && sub == 0) {
+                // height map and ground-truth map (mapper.py:338-341, 361-363)
+                const float hnew = fmaxf(h_old[b], (float)(unorder_f64(hk[b]) - agent_y));
+                mp.height_map[cell[b]] = hnew;
+                if (gt) mp.gt_map[cell[b]] = (uint32_t)gtv[b];
+                if (MODE == 1) {
+                    mp.weight_map[cell[b]] = wn;
+                    mp.unc_map[cell[b]] = ent_out;
+                }
+                const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
+                commit_cell(mp, v.palette, cell[b], id);
+            }
+        }
     }
 }
 
@@ -348,11 +349,11 @@ static void launch_reg(int mode, dim3 grid, hipStream_t s, const View &v, const 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
     dim3 grid(256, v.E), block(256);
     const bool lo = v.rule == SSMAP_RULE_LOG_ODDS;
-    const int pl = (v.C + 63) / 64;
-#define GO(MODE, PL) hipLaunchKernelGGL((k_update_prob<MODE, PL>), grid, block, 0, s, v, f.semantic_gt)
-    if (pl == 1) { if (lo) GO(2, 1); else GO(1, 1); }
-    else if (pl == 2) { if (lo) GO(2, 2); else GO(1, 2); }
-    else { if (lo) GO(2, 3); else GO(1, 3); }
+    const int cpl = (v.C + 15) / 16;
+#define GO(MODE, CPL) hipLaunchKernelGGL((k_update_prob<MODE, CPL>), grid, block, 0, s, v, f.semantic_gt)
+    if (cpl <= 3) { if (lo) GO(2, 3); else GO(1, 3); }
+    else if (cpl <= 4) { if (lo) GO(2, 4); else GO(1, 4); }
+    else { if (lo) GO(2, 10); else GO(1, 10); }
 #undef GO
 }
 

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
     __shared__ unsigned long long table_h[kSlots];
     __shared__ unsigned int table_i[kSlots];
-    __shared__ unsigned int s_count, s_base;
-    __shared__ int s_box[4];
+    __shared__ unsigned int s_base;
+    __shared__ unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
 
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
@@ -193,7 +193,6 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
 
     for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
         for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
-        if (threadIdx.x == 0) s_count = 0;
         __syncthreads();
         const bool own_inv = inv_L >= 0 && (int)(inv_L >> kSlotShift) == p;
         if (own_inv && threadIdx.x == 0) table_h[inv_L & (kSlots - 1)] = inv_key;
@@ -238,22 +237,30 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             }
         }
         __syncthreads();
-        // phase c: count, reserve, emit
-        unsigned mine = 0;
-        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) {
-            const unsigned w = table_i[s];
-            mine += (w != kNoPixel && !(w & 1u)) ? 1u : 0u;
+        // phase c: emit the surviving slots in slot order (= row-major cell order), so that
+        // neighbouring list entries are neighbouring map cells
+        constexpr int kIters = kSlots / kWinnerThreads, kWaves = kWinnerThreads / 64;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned long long balls[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const unsigned w = table_i[it * kWinnerThreads + threadIdx.x];
+            balls[it] = __ballot(w != kNoPixel && !(w & 1u));
+            if (lane == 0) s_cnt[it * kWaves + wave] = (unsigned)__popcll(balls[it]);
         }
-        if (mine) atomicAdd(&s_count, mine);
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_base = s_count ? atomicAdd(&hdr->n_winners, s_count) : 0u;
-            s_count = 0;
+            unsigned run = 0;
+            for (int k = 0; k < kIters * kWaves; ++k) { const unsigned c = s_cnt[k]; s_cnt[k] = run; run += c; }
+            s_base = run ? atomicAdd(&hdr->n_winners, run) : 0u;
         }
         __syncthreads();
-        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) {
+        unsigned n_neg = 0;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int s = it * kWinnerThreads + threadIdx.x;
+            if (!((balls[it] >> lane) & 1ull)) continue;
             const unsigned w = table_i[s];
-            if (w == kNoPixel || (w & 1u)) continue;
             const long long L = ((long long)p << kSlotShift) + s;
             const int row = (int)(L / bw) + rmin, col = (int)(L % bw) + cmin;
             lrmin = min(lrmin, row); lrmax = max(lrmax, row);
@@ -262,15 +269,18 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
             const int cell = wr * Wm + wc;
             const int pix = (int)(w >> 1);
-            if (row < 0 || col < 0) atomicAdd(&hdr->n_neg, 1u);
+            n_neg += (row < 0 || col < 0) ? 1u : 0u;
             if (write_list) {
-                const unsigned pos = s_base + atomicAdd(&s_count, 1u);
+                const unsigned pos = s_base + s_cnt[it * kWaves + wave] +
+                                     (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull));
                 if (write_target) v.target[fbase + pix] = (int)pos;
                 int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
                 const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
                 *out = make_int2((int)word, cell);
+                v.wheight[fbase + pos] = table_h[s];
             }
         }
+        if (n_neg) atomicAdd(&hdr->n_neg, n_neg);
         __syncthreads();
     }
 
@@ -281,7 +291,6 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
         atomicMin(&hdr->wrmin, lrmin); atomicMax(&hdr->wrmax, lrmax);
         atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
     }
-    (void)s_box;
 }
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which

@@ -69,7 +69,8 @@ struct View {
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
     int32_t *target;           // [E][N] slot of this pixel in the frame's update list, or -1
     float *wprob;              // [E][N][C] class probabilities of the update pixels, row = list slot
-    int32_t *winners;          // [E][N][2] (pixel, cell) pairs, unordered
+    int32_t *winners;          // [E][N][2] update list: (pixel word, cell) pairs in cell order per table
+    unsigned long long *wheight;  // [E][N] height image of each list slot's pixel
     int32_t *quad;             // [E][maxHm*maxWm][4] 1 + update pixel of each index-sign quadrant that
                                // lands on the wrapped cell (0 = none); non-zero only inside a step
     int64_t quad_stride;       // ints per env
@@ -87,6 +88,7 @@ struct View {
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;
     ssmap_params prm;
+    int32_t dbg;               // diagnostic switches (SSMAP_DEBUG), 0 in normal use
 };
 
 __host__ __device__ inline unsigned long long order_f64(double h) {

@@ -143,6 +143,147 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     }
 }
 
+// Binning: the live pixels of a frame are sorted by winner table (cell number >> 13 inside the
+// frame's cell box) into one contiguous array of 16-byte records
+//   {pixel << 1 | not-updatable, slot in table, height image lo, hi}
+// so that a winner-table block reads only its own records instead of every pixel of the frame.
+// Three small kernels: per-block histogram, prefix sums, scatter.  Record order inside a table
+// is arbitrary (the table reductions are order independent).
+// Cells of the frame's box are numbered row-major (L); runs of kInterleave consecutive cells are
+// dealt round-robin to the nparts tables so that every table sees a similar share of pixels
+// whatever the view direction:  chunk = L / 32, table = chunk % nparts,
+// slot = (chunk / nparts) * 32 + L % 32.
+constexpr int kInterleaveShift = 5, kInterleave = 1 << kInterleaveShift;
+struct BinFrame {
+    bool on;
+    int bw, rmin_b, cmin_b, nparts;
+};
+__device__ inline void split_cell(int L, int nparts, int &part, int &slot) {
+    const int chunk = L >> kInterleaveShift;
+    const int q = chunk / nparts;
+    part = chunk - q * nparts;
+    slot = (q << kInterleaveShift) | (L & (kInterleave - 1));
+}
+__device__ inline long long join_cell(int part, int slot, int nparts) {
+    const long long chunk = (long long)(slot >> kInterleaveShift) * nparts + part;
+    return (chunk << kInterleaveShift) | (slot & (kInterleave - 1));
+}
+__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
+    BinFrame f;
+    f.on = false;
+    const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
+    if (rmin > rmax) return f;
+    f.bw = cmax - cmin + 1;
+    const long long ncell = (long long)f.bw * (long long)(rmax - rmin + 1);
+    const long long np = (ncell + kSlots - 1) >> kSlotShift;
+    if (np > kMaxParts) return f;
+    f.nparts = (int)np;
+    f.rmin_b = rmin + kCoordBias;
+    f.cmin_b = cmin + kCoordBias;
+    f.on = true;
+    return f;
+}
+__device__ inline int bin_cell(const BinFrame &f, uint32_t id) {
+    const int rr = (int)((id >> kCoordBits) & kCoordMask) - f.rmin_b;
+    const int cc = (int)(id & kCoordMask) - f.cmin_b;
+    return rr * f.bw + cc;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(View v) {
+    __shared__ unsigned int cnt[kMaxParts];
+    const int e = blockIdx.y;
+    const BinFrame f = bin_frame(v.hdr + e);
+    if (!f.on) return;
+    if (threadIdx.x < kMaxParts) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 < v.N) {
+        const uint4 id4 = *reinterpret_cast<const uint4 *>(v.cellid + (int64_t)e * v.N + i0);
+        const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ids[k] != kDeadCell) {
+                int part, slot;
+                split_cell(bin_cell(f, ids[k]), f.nparts, part, slot);
+                atomicAdd(&cnt[part], 1u);
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < f.nparts)   // layout [table][block]
+        v.bin_cnt[((int64_t)e * kMaxParts + threadIdx.x) * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// One block per frame: bin_cnt[p][b] (count) -> first record index of block b's pixels for
+// table p; part_start[p] = first record of table p.
+__global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
+    __shared__ unsigned int total[kMaxParts + 1];
+    const int e = blockIdx.x;
+    const BinFrame f = bin_frame(v.hdr + e);
+    if (!f.on) return;
+    unsigned int *cnt = v.bin_cnt + (int64_t)e * kMaxParts * nbin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < f.nparts; p += 16) {
+        unsigned sum = 0;
+        for (int b = lane; b < nbin; b += 64) sum += cnt[p * nbin + b];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) total[p] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int p = 0; p < f.nparts; ++p) { const unsigned c = total[p]; total[p] = run; run += c; }
+        for (int p = f.nparts; p <= kMaxParts; ++p) total[p] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kMaxParts) v.part_start[e * (kMaxParts + 1) + threadIdx.x] = total[threadIdx.x];
+    for (int p = wave; p < f.nparts; p += 16) {
+        unsigned run = total[p];
+        for (int b0 = 0; b0 < nbin; b0 += 64) {
+            const int b = b0 + lane;
+            const unsigned c = b < nbin ? cnt[p * nbin + b] : 0u;
+            unsigned incl = c;   // inclusive wave scan
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (b < nbin) cnt[p * nbin + b] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(View v) {
+    __shared__ unsigned int cnt[kMaxParts];
+    __shared__ unsigned int base[kMaxParts];
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    const BinFrame f = bin_frame(v.hdr + e);
+    if (!f.on) return;
+    if (threadIdx.x < kMaxParts) {
+        cnt[threadIdx.x] = 0;
+        base[threadIdx.x] = threadIdx.x < f.nparts
+            ? v.bin_cnt[((int64_t)e * kMaxParts + threadIdx.x) * gridDim.x + blockIdx.x] : 0u;
+    }
+    __syncthreads();
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= v.N) return;
+    const uint4 id4 = *reinterpret_cast<const uint4 *>(v.cellid + fbase + i0);
+    const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
+    const ulonglong2 h01 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0);
+    const ulonglong2 h23 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0 + 2);
+    const unsigned long long hk[4] = {h01.x, h01.y, h23.x, h23.y};
+    uint4 *recs = v.rec + fbase;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ids[k] == kDeadCell) continue;
+        int part, slot;
+        split_cell(bin_cell(f, ids[k]), f.nparts, part, slot);
+        const unsigned pos = base[part] + atomicAdd(&cnt[part], 1u);
+        const unsigned word = ((unsigned)(i0 + k) << 1) | ((ids[k] & kUpdBit) ? 0u : 1u);
+        recs[pos] = make_uint4(word, (unsigned)slot, (unsigned)hk[k], (unsigned)(hk[k] >> 32));
+    }
+}
+
 // One block = one table of kSlots consecutive cells of the frame's cell bounding box
 // (cells are numbered row-major inside the box).  Every block scans all cell ids of
 // its frame and keeps the pixels that fall into its table:
@@ -150,6 +291,7 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
 //   phase b   table_i[slot] = min pixel index among the pixels that reach that max
 //   phase c   slots whose winner passes the filters are appended to the update list
 // Integer max / min are order independent, so the result is deterministic.
+template <bool RUNS>
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
     __shared__ unsigned long long table_h[kSlots];
     __shared__ unsigned int table_i[kSlots];
@@ -168,6 +310,9 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
     const int nparts = (int)((ncell + kSlots - 1) >> kSlotShift);
     const int rmin_b = rmin + kCoordBias, cmin_b = cmin + kCoordBias;
+    // frames whose cell box needs at most kMaxParts tables are binned (k_bin) and read as runs;
+    // larger boxes fall back to scanning every cell id once per table
+    if (RUNS != (nparts <= kMaxParts)) return;
 
     // the cell all invalid-depth pixels fall into (they sit at the camera position,
     // mapper.py:28-31) and their common height
@@ -186,19 +331,43 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
         }
     }
 
+    int inv_part = -1, inv_slot = 0;
+    if (inv_L >= 0) {
+        if (RUNS) split_cell((int)inv_L, nparts, inv_part, inv_slot);
+        else { inv_part = (int)(inv_L >> kSlotShift); inv_slot = (int)(inv_L & (kSlots - 1)); }
+    }
     const uint4 *ids4 = reinterpret_cast<const uint4 *>(v.cellid + fbase);
     const unsigned long long *hk = v.horder + fbase;
     const int n4 = v.N >> 2;
+    // binned records of this frame, contiguous per table
+    const uint4 *recs = v.rec + fbase;
+    const unsigned int *part_start = v.part_start + e * (kMaxParts + 1);
+    constexpr int kRunBatch = 4;
     int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
 
     for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
+        const unsigned rec_beg = RUNS ? part_start[p] : 0u, rec_end = RUNS ? part_start[p + 1] : 0u;
         for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
         __syncthreads();
-        const bool own_inv = inv_L >= 0 && (int)(inv_L >> kSlotShift) == p;
-        if (own_inv && threadIdx.x == 0) table_h[inv_L & (kSlots - 1)] = inv_key;
+        const bool own_inv = inv_L >= 0 && inv_part == p;
+        if (own_inv && threadIdx.x == 0) table_h[inv_slot] = inv_key;
         __syncthreads();
 
         // phase a
+        if (RUNS) {
+            for (unsigned t0 = rec_beg + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
+                uint4 rec[kRunBatch];
+#pragma unroll
+                for (int u = 0; u < kRunBatch; ++u) {
+                    const unsigned t = t0 + u * kWinnerThreads;
+                    if (t < rec_end) rec[u] = recs[t];
+                }
+#pragma unroll
+                for (int u = 0; u < kRunBatch; ++u)
+                    if (t0 + u * kWinnerThreads < rec_end)
+                        atomicMax(&table_h[rec[u].y], ((unsigned long long)rec[u].w << 32) | rec[u].z);
+            }
+        } else {
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
             const uint4 id4 = ids4[q];
             const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
@@ -212,13 +381,29 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
                 if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], hk[4 * q + k]);
             }
         }
+        }
         __syncthreads();
         // phase b
         if (own_inv && threadIdx.x == 0) {
-            const int s = (int)(inv_L & (kSlots - 1));
+            const int s = inv_slot;
             if (table_h[s] == inv_key) table_i[s] = (min_inv << 1) | 1u;
         }
         __syncthreads();
+        if (RUNS) {
+            for (unsigned t0 = rec_beg + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
+                uint4 rec[kRunBatch];
+#pragma unroll
+                for (int u = 0; u < kRunBatch; ++u) {
+                    const unsigned t = t0 + u * kWinnerThreads;
+                    if (t < rec_end) rec[u] = recs[t];
+                }
+#pragma unroll
+                for (int u = 0; u < kRunBatch; ++u)
+                    if (t0 + u * kWinnerThreads < rec_end &&
+                        table_h[rec[u].y] == (((unsigned long long)rec[u].w << 32) | rec[u].z))
+                        atomicMin(&table_i[rec[u].y], rec[u].x);
+            }
+        } else {
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
             const uint4 id4 = ids4[q];
             const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
@@ -235,6 +420,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
                         atomicMin(&table_i[s], ((unsigned)(4 * q + k) << 1) | ((id & kUpdBit) ? 0u : 1u));
                 }
             }
+        }
         }
         __syncthreads();
         // phase c: emit the surviving slots in slot order (= row-major cell order), so that
@@ -261,7 +447,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             const int s = it * kWinnerThreads + threadIdx.x;
             if (!((balls[it] >> lane) & 1ull)) continue;
             const unsigned w = table_i[s];
-            const long long L = ((long long)p << kSlotShift) + s;
+            const long long L = RUNS ? join_cell(p, s, nparts) : ((long long)p << kSlotShift) + s;
             const int row = (int)(L / bw) + rmin, col = (int)(L % bw) + cmin;
             lrmin = min(lrmin, row); lrmax = max(lrmax, row);
             lcmin = min(lcmin, col); lcmax = max(lcmax, col);
@@ -344,7 +530,13 @@ void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s) {
 void launch_winners(const View &v, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
+    const int nbin = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
+    dim3 grid_bin(nbin, v.E);
+    hipLaunchKernelGGL(k_bin_count, grid_bin, dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_bin_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
+    hipLaunchKernelGGL(k_bin_scatter, grid_bin, dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_winners<true>, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
+    hipLaunchKernelGGL(k_winners<false>, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
 }
 
 }  // namespace ssmap

@@ -22,6 +22,7 @@ constexpr int kSlots = 8192;                  // cells per LDS winner table
 constexpr int kSlotShift = 13;
 constexpr int kGeomPixPerBlock = 1024;        // geometry kernel: 256 threads x 4 pixels
 constexpr int kWinnerThreads = 1024;
+constexpr int kMaxParts = 64;                // binned path: tables per frame (cell box <= 512 Ki cells)
 constexpr int kWinnerPartsPerEnv = 16;        // blocks launched per env for the winner kernel
 
 // Per-env, per-step geometry constants: the host derives them from the two pose vectors
@@ -67,6 +68,9 @@ struct View {
     FrameHeader *hdr;
     uint32_t *cellid;          // [E][N]
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
+    uint4 *rec;                // [E][N] binned pixel records (k_bin)
+    unsigned int *bin_cnt;     // [E][N/1024][kMaxParts] per-block table counts, then record bases
+    unsigned int *part_start;  // [E][kMaxParts+1] first record of each table
     int32_t *target;           // [E][N] slot of this pixel in the frame's update list, or -1
     float *wprob;              // [E][N][C] class probabilities of the update pixels, row = list slot
     int32_t *winners;          // [E][N][2] update list: (pixel word, cell) pairs in cell order per table

@@ -225,7 +225,6 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.envs = eng->d_envs; v.poses = eng->d_poses; v.hdr = eng->d_hdr;
     v.lut = eng->d_lut; v.pool_ids = eng->d_pool_ids; v.pool_count = eng->d_pool_count;
     v.cur_overlay = 0;
-    if (const char *d = getenv("SSMAP_DEBUG")) v.dbg = atoi(d);
     *out = eng;
     return SSMAP_OK;
 }

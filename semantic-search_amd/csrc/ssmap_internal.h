@@ -92,7 +92,6 @@ struct View {
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;
     ssmap_params prm;
-    int32_t dbg;               // diagnostic switches (SSMAP_DEBUG), 0 in normal use
 };
 
 __host__ __device__ inline unsigned long long order_f64(double h) {

@@ -1,0 +1,42 @@
+"""The C-ABI library loads on a machine without a GPU and exports every entry point that
+include/ssmap.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "ssmap.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssmap_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import semantic_search_amd as ssa
+    names = declared_functions()
+    assert "ssmap_step" in names and "ssmap_create" in names and len(names) >= 12
+    lib = ctypes.CDLL(ssa._capi.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in ssmap.h but not exported"
+    assert set(ssa._capi.EXPORTS) == set(names)
+
+
+def test_struct_sizes_match_the_header_layout():
+    import semantic_search_amd as ssa
+    c = ssa._capi
+    assert ctypes.sizeof(c.Config) == 9 * 4 + 2 * 4 + 4 + 4 * 8      # 9 ints, 2 floats, pad, 4 doubles
+    assert ctypes.sizeof(c.EnvMaps) == 8 + 3 * 8 + 11 * 8
+    assert ctypes.sizeof(c.Params) == 7 * 4 + 4 + 2 * 8
+    assert ctypes.sizeof(c.Frames) == 11 * 8
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import pytest
+    import torch
+    import semantic_search_amd as ssa
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        ssa.MapEngine(1, (48, 64), depth_hfov=59.0, depth_range=(0.5, 5.0))

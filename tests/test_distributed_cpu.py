@@ -1,0 +1,56 @@
+"""Env sharding and the final metric reduce on two gloo ranks (the N>1 path of bench.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from semantic_search_amd import sharding
+
+
+def _episodes_for(env):
+    rng = np.random.default_rng(env)
+    return [dict(success=float(rng.random() < 0.7), spl=float(rng.random()), length=float(rng.integers(10, 500)),
+                 fp_found=float(rng.random() < 0.1), fn_found=float(rng.random() < 0.1),
+                 fp_detections=float(rng.integers(0, 4)), fn_detections=float(rng.integers(0, 2)),
+                 goal=int(rng.integers(0, 6))) for _ in range(3)]
+
+
+def _worker(rank, world, port, n_envs, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = sharding.shard_envs(n_envs, rank, world)
+    eps = [ep for env in mine for ep in _episodes_for(env)]
+    res = sharding.reduce_metrics(sharding.pack_metrics(eps))
+    slowest = sharding.max_over_ranks(1.0 + rank)
+    torch.save({"res": res, "slowest": slowest, "mine": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_cover_every_env_once():
+    for n, w in ((16, 1), (16, 2), (17, 4), (1024, 8), (3, 8)):
+        seen = [e for r in range(w) for e in sharding.shard_envs(n, r, w)]
+        assert seen == list(range(n))
+        sizes = [len(sharding.shard_envs(n, r, w)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_reduce_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n_envs, world = 7, 2
+    mp.spawn(_worker, args=(world, port, n_envs, str(tmp_path)), nprocs=world, join=True)
+    everything = [ep for env in range(n_envs) for ep in _episodes_for(env)]
+    want = sharding.reduce_metrics(sharding.pack_metrics(everything))
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
+        assert got["slowest"] == 2.0
+        assert got["res"]["n_episodes"] == want["n_episodes"] == 21.0
+        for k in sharding.METRIC_FIELDS[1:]:
+            assert abs(got["res"][k] - want[k]) < 1e-12
+        assert np.allclose(got["res"]["per_goal_success"], want["per_goal_success"], equal_nan=True)

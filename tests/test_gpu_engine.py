@@ -1,0 +1,281 @@
+"""HIP engine against the CPU oracle on seeded inputs, through the C ABI.
+
+Bars: update set (cell indices), integer maps and found flags bit-exact; float32 state within
+rtol 1e-5 / atol 1e-6.  Where a label depends on an argmax over floating-point values that the
+two implementations round differently, a mismatch is accepted only if the two leading values
+are within 1e-5 relative of each other, and the number of such cells is reported.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mapper_oracle as mo
+from oracle import stage1_oracle as s1
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+BOUNDS_480 = np.array([0.0, 0.0, 0.0, 14.39, 3.0, 14.39])
+
+
+def _close(got, want, name, rtol=RTOL, atol=ATOL):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern"
+    assert np.array_equal(np.isinf(got), np.isinf(want)), f"{name}: inf pattern"
+    fin = np.isfinite(want)
+    err = np.abs(got[fin] - want[fin])
+    tol = atol + rtol * np.abs(want[fin])
+    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} (ratio {(err / tol).max():.2f})"
+
+
+def _to_dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def _top2_margin(vectors):
+    srt = np.sort(vectors.astype(np.float64), axis=-1)
+    return (srt[..., -1] - srt[..., -2]) / np.maximum(np.abs(srt[..., -1]), 1e-30)
+
+
+@pytest.mark.parametrize("n_classes,temperature", [(40, 3.2), (150, 2.5), (12, 1.0)])
+def test_stage1_matches_oracle(n_classes, temperature):
+    import semantic_search_amd as ssa
+    h, w = 120, 160
+    rng = np.random.default_rng(n_classes)
+    logits = (3.0 * rng.standard_normal((2, n_classes, h, w))).astype(np.float32)
+    lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
+    eng = ssa.MapEngine(2, (h, w), depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+                        prob_aggregate="height_map_argmax", seg_model_n_classes=n_classes,
+                        max_map_hw=(100, 100))
+    eng.set_schema(lut)
+    out = eng.stage1(_to_dev(logits, np.float32), temperature, want_probs=True)
+    torch.cuda.synchronize()
+    for e in range(2):
+        want = s1.predict_tail(logits[e], temperature, lut)
+        probs = out["semantic_prob"][e].cpu().numpy()
+        _close(probs, want["semantic_prob"], "semantic_prob", atol=1e-9)
+        _close(out["semantic_unc"][e].cpu().numpy(), want["semantic_unc"], "semantic_unc")
+        sem = out["semantic"][e].cpu().numpy()
+        bad = sem != want["semantic"]
+        if bad.any():   # only genuine argmax ties may differ
+            margins = _top2_margin(np.moveaxis(want["semantic_prob"], 0, -1)[bad])
+            assert (margins < 1e-5).all()
+        ok = ~bad
+        _close(out["semantic_max_prob"][e].cpu().numpy()[ok], want["semantic_max_prob"][ok], "semantic_max_prob")
+    eng.close()
+
+
+def _run_pair(rule, n_classes, temperature, n_frames, hw, from_logits, attrs=None, filter_goal_prob=None,
+              seed=0, bounds=BOUNDS_480, center=7.2):
+    """Drives the engine (E=1, device-resident inputs) and the oracle over the same frames."""
+    import semantic_search_amd as ssa
+    h, w = hw
+    lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=n_classes, filter_goal_prob=filter_goal_prob)
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    eng = ssa.MapEngine(1, hw, max_map_hw=ssa.map_size(bounds, 0.03), **kw)
+    eng.set_schema(lut)
+    for k, v in (attrs or {}).items():
+        setattr(ref, k, v)
+        setattr(eng.params, k, v)
+    ref.reset(bounds)
+    maps = eng.reset_env(0, bounds)
+    rng = np.random.default_rng(seed)
+    prng = np.random.default_rng(seed + 100)
+    log = []
+    for i in range(n_frames):
+        frame = scenes.uniform_frame(rng, h, w, n_classes, temperature, lut=lut, with_probs=False)
+        agent, cam = scenes.make_pose(center, 0.0, center, prng.uniform(0, 2 * np.pi))
+        st = s1.predict_tail(frame["logits"], temperature, lut)
+        obs = {"depth": frame["depth"].copy(), "semantic_gt": frame["semantic_gt"], "objectgoal": np.array([0]),
+               "agent_position_and_rotation": agent, "camera_position_and_rotation": cam,
+               "semantic": st["semantic"], "semantic_prob": st["semantic_prob"],
+               "semantic_unc": st["semantic_unc"], "semantic_max_prob": st["semantic_max_prob"]}
+        found_ref = ref.update(obs)
+        depth = _to_dev(frame["depth"][None], np.float32)
+        gt = _to_dev(frame["semantic_gt"][None], np.int32)
+        sem = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+        unc = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        maxp = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        if from_logits:
+            eng.step(depth, agent[None], cam[None], [3], logits=_to_dev(frame["logits"][None], np.float32),
+                     temperature=temperature, semantic=sem, semantic_unc=unc, semantic_max_prob=maxp,
+                     semantic_gt=gt)
+        else:
+            eng.step(depth, agent[None], cam[None], [3], probs=_to_dev(st["semantic_prob"][None], np.float32),
+                     semantic=_to_dev(st["semantic"][None], np.int32),
+                     semantic_unc=_to_dev(st["semantic_unc"][None], np.float32),
+                     semantic_max_prob=_to_dev(st["semantic_max_prob"][None], np.float32), semantic_gt=gt)
+        found, status, n_upd = eng.results()
+        assert status[0] == 0
+        pix, _ = eng.update_list(0, int(n_upd[0]))
+        assert np.array_equal(pix, ref.last_update_pixels), f"frame {i}: update set"
+        assert np.array_equal(depth[0].cpu().numpy(), obs["depth"]), "depth sentinels"
+        log.append((bool(found[0]), bool(found_ref)))
+    return eng, maps, ref, log
+
+
+@pytest.mark.parametrize("rule,from_logits", [
+    ("height_map_log_odds", True), ("height_map_avg_prob", True), ("height_map_avg_prob", False),
+    ("height_map_w_avg_prob", True), ("height_map_w2_avg_prob", False)])
+def test_full_size_probability_rules(rule, from_logits):
+    """640x480x40 benchmark-recipe frames, two frames, fused state vs the oracle."""
+    eng, maps, ref, log = _run_pair(rule, 40, 3.2, 2, (480, 640), from_logits,
+                                    attrs=dict(entropy_threshold=0.43759))
+    name = "log_odds_seg_map" if "log_odds" in rule else "avg_prob_seg_map"
+    got = maps[name].cpu().numpy()
+    want = getattr(ref, name)
+    # log-odds of two frames: values ~ +-20, differences of float32 softmax roundings ~1e-6 abs
+    _close(got, want, name, rtol=2e-5 if from_logits else RTOL, atol=2e-5 if "log_odds" in rule else ATOL)
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+    sem = maps["semantic_map"].cpu().numpy().view(np.uint32)
+    bad = sem != ref.semantic_map
+    if bad.any():   # labels may differ only where the fused vector's two leaders tie
+        margins = _top2_margin(want[bad])
+        assert (margins < 1e-4).all(), f"{bad.sum()} label mismatches, min margin {margins.max():.2e}"
+    assert bad.sum() <= 3
+    if "avg" in rule:
+        _close(maps["unc_map"].cpu().numpy(), ref.unc_map, "unc_map", rtol=1e-4, atol=1e-5)
+    if not bad.any():
+        assert [a for a, _ in log] == [b for _, b in log]
+    eng.close()
+
+
+def test_segformer_style_150_classes_w2():
+    eng, maps, ref, log = _run_pair("height_map_w2_avg_prob", 150, 2.5, 2, (120, 160), True,
+                                    attrs=dict(entropy_threshold=0.482), bounds=BOUNDS_480)
+    _close(maps["avg_prob_seg_map"].cpu().numpy(), ref.avg_prob_seg_map, "avg_prob_seg_map", rtol=1e-4, atol=1e-6)
+    _close(maps["avg_prob_weight_map"].cpu().numpy(), ref.avg_prob_weight_map, "weight", rtol=1e-4)
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    eng.close()
+
+
+@pytest.mark.parametrize("rule,attrs,filt", [
+    ("height_map_goal_decay", dict(goal_decay=0.8931, goal_mark=1.5408), 0.38158),
+    ("height_map_prob_hv", dict(hv_ratio=0.887, hv_min_views=5, hv_limit_obj_view_dist=4.13219), None),
+    ("height_map_hv", dict(hv_ratio=0.5, hv_min_views=1, hv_limit_obj_view_dist=0.0), 0.3),
+    ("height_map_argmax", {}, 0.53446)])
+def test_full_size_label_rules_from_logits(rule, attrs, filt):
+    """Label rules fed by the engine's own stage 1 (logits in): labels come from a float argmax,
+    so the comparison feeds the oracle the ENGINE's stage-1 outputs and demands exact maps."""
+    import semantic_search_amd as ssa
+    h, w, c, t = 480, 640, 40, 3.2
+    lut = scenes.schema_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=c, filter_goal_prob=filt)
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=(480, 480), **kw)
+    eng.set_schema(lut)
+    for k, v in attrs.items():
+        setattr(ref, k, v)
+        setattr(eng.params, k, v)
+    ref.reset(BOUNDS_480)
+    maps = eng.reset_env(0, BOUNDS_480)
+    rng, prng = np.random.default_rng(5), np.random.default_rng(6)
+    for i in range(3):
+        frame = scenes.uniform_frame(rng, h, w, c, t, lut=lut, with_probs=False)
+        agent, cam = scenes.make_pose(7.2, 0.0, 7.2, prng.uniform(0, 2 * np.pi))
+        depth = _to_dev(frame["depth"][None], np.float32)
+        sem = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+        unc = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        maxp = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        eng.step(depth, agent[None], cam[None], [3], logits=_to_dev(frame["logits"][None], np.float32),
+                 temperature=t, semantic=sem, semantic_unc=unc, semantic_max_prob=maxp,
+                 semantic_gt=_to_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        obs = {"depth": frame["depth"].copy(), "semantic_gt": frame["semantic_gt"], "objectgoal": np.array([0]),
+               "agent_position_and_rotation": agent, "camera_position_and_rotation": cam,
+               "semantic": sem[0].cpu().numpy(), "semantic_unc": unc[0].cpu().numpy(),
+               "semantic_max_prob": maxp[0].cpu().numpy()}
+        found_ref = ref.update(obs)
+        pix, _ = eng.update_list(0, int(n_upd[0]))
+        assert np.array_equal(pix, ref.last_update_pixels)
+        assert bool(found[0]) == bool(found_ref), f"frame {i}"
+        assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map), f"frame {i}"
+    for nm in ("height_map", "gt_map", "goal_map", "background_map", "hits", "views", "unc_map"):
+        if nm in maps and getattr(ref, nm, None) is not None:
+            got = maps[nm].cpu().numpy()
+            if got.dtype == np.int32:
+                got = got.view(np.uint32)
+            assert np.array_equal(got, getattr(ref, nm)), nm
+    eng.close()
+
+
+def test_batched_engine_equals_independent_engines():
+    """E = 3 envs with different map sizes and poses in one call == three E = 1 engines."""
+    import semantic_search_amd as ssa
+    h, w, c = 96, 128, 8
+    lut = scenes.small_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
+    bounds = [np.array([0, 0, 0, 4.5, 2.5, 4.5]), np.array([-1.0, 0, -2.0, 5.0, 2.5, 3.1]),
+              np.array([0.3, 0, 0.2, 3.0, 2.5, 6.0])]
+    big = ssa.MapEngine(3, (h, w), max_map_hw=(200, 200), **kw)
+    big.set_schema(lut)
+    singles = []
+    for e in range(3):
+        big.reset_env(e, bounds[e])
+        s = ssa.MapEngine(1, (h, w), max_map_hw=(200, 200), **kw)
+        s.set_schema(lut)
+        s.reset_env(0, bounds[e])
+        singles.append(s)
+    rng = np.random.default_rng(3)
+    for i in range(3):
+        frames, ag, cam = [], [], []
+        for e in range(3):
+            a, cm = scenes.make_pose(1.5 + 0.2 * e, 0.0, 1.2 + 0.3 * i, rng.uniform(0, 6.28))
+            frames.append(scenes.room_frame(rng, h, w, c, 1.0, cm, lut=lut))
+            ag.append(a)
+            cam.append(cm)
+        depth = np.stack([f["depth"] for f in frames])
+        probs = np.stack([f["semantic_prob"] for f in frames])
+        gt = np.stack([f["semantic_gt"] for f in frames])
+        big.step(_to_dev(depth, np.float32), np.stack(ag), np.stack(cam), [3, 4, 3],
+                 probs=_to_dev(probs, np.float32), semantic_gt=_to_dev(gt, np.int32))
+        fb, sb, nb = big.results()
+        for e in range(3):
+            singles[e].step(_to_dev(depth[e:e + 1], np.float32), ag[e][None], cam[e][None], [[3, 4, 3][e]],
+                            probs=_to_dev(probs[e:e + 1], np.float32), semantic_gt=_to_dev(gt[e:e + 1], np.int32))
+            f1, s1_, n1 = singles[e].results()
+            assert (fb[e], sb[e], nb[e]) == (f1[0], s1_[0], n1[0])
+    for e in range(3):
+        for nm, t in big.maps[e].items():
+            assert torch.equal(t, singles[e].maps[0][nm]), (e, nm)
+    big.close()
+    for s in singles:
+        s.close()
+
+
+def test_index_below_minus_dim_is_reported_like_numpy():
+    """A selected cell with index < -dim makes the reference raise IndexError (mapper.py:338)."""
+    import semantic_search_amd as ssa
+    h, w = 48, 64
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    m.reset(np.array([4.0, 0.0, 4.0, 4.6, 2.5, 4.6]))      # 20 x 20 cells; camera 3 m outside
+    agent, cam = scenes.make_pose(1.0, 0.0, 1.0, np.pi + 0.75)
+    frame = scenes.room_frame(np.random.default_rng(0), h, w, 0, 1.0, cam)
+    obs = scenes.make_obs(frame, agent, cam)
+    ref = mo.OracleMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    ref.reset(np.array([4.0, 0.0, 4.0, 4.6, 2.5, 4.6]))
+    with pytest.raises(IndexError):
+        ref.update(scenes.make_obs(frame, agent, cam))
+    with pytest.raises(IndexError):
+        m.update_map(obs, None)
+
+
+def test_frame_without_any_valid_depth_updates_nothing():
+    import semantic_search_amd as ssa
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    m.reset(np.array([0.0, 0.0, 0.0, 3.0, 2.5, 3.0]))
+    agent, cam = scenes.make_pose(1.5, 0.0, 1.5, 0.3)
+    obs = {"depth": np.full((48, 64), 5.0, np.float32), "semantic": np.ones((48, 64), np.int32),
+           "agent_position_and_rotation": agent, "camera_position_and_rotation": cam,
+           "objectgoal": np.array([1])}
+    _, found = m.update_map(obs, None)
+    assert found is None and m.last_n_updates == 0
+    assert not obs["depth"].any() and not m.semantic_map.any()
+    assert np.isneginf(m.height_map).all()

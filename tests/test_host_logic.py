@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference interface (no GPU needed)."""
+import numpy as np
+import pytest
+
+import semantic_search_amd as ssa
+from semantic_search_amd import engine as eng
+from oracle import mapper_oracle as mo
+from oracle import raster
+
+
+def test_map_size_uses_float64_ceil():
+    # 14.4 / 0.03 is 480.00000000000006 in float64 -> 481 (mapper.py:197-204)
+    assert ssa.map_size([0, 0, 0, 14.4, 3, 14.4], 0.03) == (481, 481)
+    assert ssa.map_size([0, 0, 0, 14.39, 3, 14.39], 0.03) == (480, 480)
+    assert ssa.map_size([0, 0, 0, 28.79, 3, 28.79], 0.03) == (960, 960)
+    assert ssa.map_size([-1.0, 0, 2.0, 3.5, 3, 2.9], 0.03) == (30, 150)   # rows <-> z, cols <-> x
+
+
+def test_focal_lengths_use_the_linear_vfov():
+    fx, fy = ssa.focal_lengths(480, 640, 59.0)
+    hfov = np.deg2rad(59.0)
+    assert fx == 640 / (2.0 * np.tan(hfov / 2.0))
+    assert fy == 480 / (2.0 * np.tan((480 / 640 * hfov) / 2.0))
+    assert (fx, fy) == mo.focal_lengths(480, 640, 59.0)
+
+
+def test_colormap_matches_oracle_palette():
+    assert np.array_equal(ssa.colormap(12), mo.palette(12))
+    assert ssa.colormap(12)[1].tolist() == [128, 0, 0] and ssa.colormap(12)[2].tolist() == [0, 128, 0]
+
+
+@pytest.mark.parametrize("name,prob,expect", [
+    ("height_map_avg_prob", True, ("avg_prob", True)),
+    ("log_odds", True, ("log_odds", False)),
+    ("height_map_prob_hv", True, ("prob_hv", True)),
+    ("height_map_argmax", False, ("direct", True)),
+    ("argmax", False, ("direct", False)),
+    ("height_map_goal_decay", False, ("direct", False)),
+])
+def test_split_rule(name, prob, expect):
+    assert eng.split_rule(name, prob) == expect
+
+
+def test_split_rule_rejects_unknown_rules():
+    with pytest.raises(RuntimeError, match="Invalid prob_aggregate"):
+        eng.split_rule("height_map_median", True)
+
+
+def test_rule_params_track_late_mutation():
+    p = ssa.RuleParams(entropy_threshold=0.5, filter_goal_prob=None, goal_decay=0.9, goal_mark=2.0,
+                       hv_ratio=0.5, hv_min_views=10, hv_limit_obj_view_dist=0.0, found_dist_m=1.0)
+    assert p.dirty
+    packed = p.pack()
+    assert packed.use_filter == 0 and abs(packed.goal_decay - 0.9) < 1e-7
+    object.__setattr__(p, "dirty", False)
+    p.filter_goal_prob = 0.38158
+    assert p.dirty and p.pack().use_filter == 1
+
+
+def test_mapper_exposes_rule_attributes_like_the_reference():
+    # callers gate their overrides on hasattr (eval_objnav.py:118-129)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              seg_model_n_classes=40)
+    hv = ssa.SemanticMapper(prob_aggregate="height_map_hv", **kw)
+    assert (hv.hv_ratio, hv.hv_min_views, hv.hv_limit_obj_view_dist) == (0.5, 10, 0.0)
+    assert not hasattr(hv, "goal_decay") and not hasattr(hv, "entropy_threshold")
+    avg = ssa.SemanticMapper(prob_aggregate="height_map_avg_prob", entropy_threshold=0.4, **kw)
+    assert avg.entropy_threshold == 0.4 and not hasattr(avg, "hv_ratio")
+    gd = ssa.SemanticMapper(prob_aggregate="height_map_goal_decay", **kw)
+    assert (gd.goal_decay, gd.goal_mark) == (0.9, 2.0)
+    assert gd.goal2sem_id.tolist() == [3, 4, 5, 6, 7, 8] and gd.path_id == 10
+    assert gd.unc_map is None        # before reset, like the reference
+    with pytest.raises(RuntimeError, match="Invalid prob_aggregate"):
+        ssa.SemanticMapper(prob_aggregate="height_map_bogus", **kw)
+
+
+def test_world2map_and_map2world():
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    lower = np.array([-1.0, 0.0, 2.0])
+    pts = np.array([[0.0, 1.0, 2.0], [-1.01, 0.0, 2.95], [0.5, 0.0, 1.99]])
+    cells = m.world2map(pts, lower)
+    assert cells.dtype == np.int64
+    assert cells.tolist() == mo.cell_of(pts, lower, 0.03).tolist()
+    assert cells[1].tolist() == [31, -1] and cells[2].tolist() == [-1, 50]
+    back = m.map2world(cells, lower)
+    assert np.allclose(back[0], [cells[0][1] * 0.03 - 1.0, cells[0][0] * 0.03 + 2.0])
+
+
+@pytest.mark.parametrize("radius", [0, 1, 3, 16, 33])
+def test_found_disk_matches_oracle_raster(radius):
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                           success_dist_m=radius * 0.03 + 0.001)
+    m.map_bounds = np.array([0, 0, 0, 3.0, 3, 3.0])
+    for center in ((50, 50), (2, 97), (99, 0)):
+        rr, cc = m._disk_indices(center)
+        want = raster.disk_mask((100, 100), center[0], center[1], radius)
+        got = np.zeros((100, 100), dtype=bool)
+        got[rr, cc] = True
+        assert np.array_equal(got, want)

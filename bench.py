@@ -209,10 +209,18 @@ def main():
     if rank == 0:
         k_mean = float(n_upd.mean())
         geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, k_mean, prob_rule)
-        # dominant kernel = the streaming stage-1 (+ rule) pass, stage group [2]
+        # dominant kernel = the streaming stage-1 pass (k_stream_*: one launch per step, stage
+        # group [2]): reads the [E][C][H][W] logits once, writes semantic / unc / max_prob
         dom_ms = stage_ms[2] / max(n_prof, 1)
-        dom_bytes = (s1_b + (state_b if prob_rule else 0)) * E
+        dom_bytes = s1_b * E
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get(f"E{E}", {}).get("k_stream_bytes_per_launch")
+        except OSError:
+            pass
+        names = ("geometry", "bin_and_winners", "stream_stage1", "rule_update", "found")
         line = {
             "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",
             "value": frames_total / elapsed,
@@ -233,14 +241,11 @@ def main():
                        "algorithmic_MB_per_frame": (geo_b + s1_b + state_b) / 1e6,
                        "whole_path_frac_of_hbm_peak":
                            (geo_b + s1_b + state_b) * (frames_total / world / elapsed) / 1e9 / HBM_PEAK_GBS},
-            "roofline": {"bound": "hbm", "kernel": "k_stream (stage 1 + rule update)",
+            "roofline": {"bound": "hbm", "kernel": "k_stream_reg (stage 1 fused softmax/entropy pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms},
-            "stage_ms_per_step": {"geometry": stage_ms[0] / max(n_prof, 1),
-                                  "winners": stage_ms[1] / max(n_prof, 1),
-                                  "stream_rule": stage_ms[2] / max(n_prof, 1),
-                                  "found": stage_ms[3] / max(n_prof, 1)},
+            "stage_ms_per_step": {nm: stage_ms[k] / max(n_prof, 1) for k, nm in enumerate(names)},
         }
         if world == 1 and not args.no_cpu_baseline:
             fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0)

@@ -161,10 +161,11 @@ int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status,
 int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev);
 
 /* Measurement hooks (no counterpart in the reference).  After ssmap_profile_begin the next
- * `max_steps` calls of ssmap_step record HIP events on their stream around four stage
- * groups: [0] header reset + geometry, [1] tallest-per-cell + wrap resolution,
- * [2] stage 1 + rule update, [3] found decision.  ssmap_profile_read waits for `stream`,
- * returns the summed milliseconds per group and the number of recorded steps, and rearms. */
+ * `max_steps` calls of ssmap_step record HIP events on their stream around five stage
+ * groups: [0] header reset + geometry, [1] binning + tallest-per-cell + wrap resolution,
+ * [2] the streaming stage-1 kernel (one launch), [3] rule update, [4] found decision.
+ * ssmap_profile_read waits for `stream`, returns the summed milliseconds per group
+ * (stage_ms[5]) and the number of recorded steps, and rearms. */
 int ssmap_profile_begin(ssmap_engine *eng, int32_t max_steps);
 int ssmap_profile_read(ssmap_engine *eng, double *stage_ms, int32_t *n_steps, void *stream);
 

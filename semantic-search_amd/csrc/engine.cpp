@@ -118,7 +118,7 @@ struct ssmap_engine {
     int prof_capacity = 0, prof_steps = 0;
 };
 
-constexpr int kProfMarks = 5;   // 4 stage intervals
+constexpr int kProfMarks = 6;   // 5 stage intervals
 
 extern "C" {
 
@@ -381,14 +381,16 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     MARK(2);
     if (prob_rule) {
         launch_stream(v, *f, true, nullptr, stream);
+        MARK(3);
         launch_update_prob(v, *f, stream);
     } else {
         if (f->logits) launch_stream(v, *f, false, nullptr, stream);
+        MARK(3);
         launch_label_rules(v, *f, stream);
     }
-    MARK(3);
-    launch_found(v, stream);
     MARK(4);
+    launch_found(v, stream);
+    MARK(5);
 #undef MARK
     HIP_TRY(hipGetLastError());
     v.cur_overlay ^= 1;

@@ -296,8 +296,8 @@ class MapEngine:
         _capi.check(self.lib.ssmap_profile_begin(self._h, int(max_steps)))
 
     def profile_read(self):
-        """(ms per stage group summed over the recorded steps [4], number of steps)."""
-        ms = np.zeros(4, dtype=np.float64)
+        """(ms per stage group summed over the recorded steps [5], number of steps)."""
+        ms = np.zeros(5, dtype=np.float64)
         n = C.c_int32(0)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream

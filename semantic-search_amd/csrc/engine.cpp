@@ -129,7 +129,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -179,6 +179,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.n_schema = c.n_schema; v.rule = c.rule; v.use_height = c.use_height_map;
     v.depth_min = c.depth_min; v.depth_max = c.depth_max;
     v.fx = c.fx; v.fy = c.fy; v.p2m = c.pixel2meter;
+    v.inv_fx = 1.0 / c.fx; v.inv_fy = 1.0 / c.fy; v.inv_p2m = 1.0 / c.pixel2meter;
     const size_t EN = (size_t)v.E * v.N;
     int rc = SSMAP_OK;
 #define TRY_ALLOC(call) do { rc = (call); if (rc != SSMAP_OK) { ssmap_destroy(eng); return rc; } } while (0)
@@ -187,6 +188,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
     TRY_ALLOC(dev_alloc(&v.cellid, EN));
     TRY_ALLOC(dev_alloc(&v.horder, EN));
+    TRY_ALLOC(dev_alloc(&v.geo_part, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * 8));
     TRY_ALLOC(dev_alloc(&v.rec, EN));
     TRY_ALLOC(dev_alloc(&v.bin_cnt, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * kMaxParts));
     TRY_ALLOC(dev_alloc(&v.part_start, (size_t)v.E * (kMaxParts + 1)));
@@ -373,7 +375,6 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         marks = eng->prof_events.data() + (size_t)kProfMarks * eng->prof_steps++;
 #define MARK(i) do { if (marks) HIP_TRY(hipEventRecord(marks[i], stream)); } while (0)
     MARK(0);
-    launch_begin_step(v, stream);
     launch_geometry(v, *f, stream);
     MARK(1);
     launch_winners(v, stream);

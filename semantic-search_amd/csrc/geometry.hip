@@ -12,24 +12,6 @@
 
 namespace ssmap {
 
-__global__ void k_begin_step(View v) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= v.E) return;
-    FrameHeader h;
-    h.rmin = h.cmin = h.wrmin = h.wcmin = 0x7FFFFFFF;
-    h.rmax = h.cmax = h.wrmax = h.wcmax = (int32_t)0x80000000;
-    h.min_invalid_pixel = kNoPixel;
-    h.n_winners = 0;
-    h.status = 0;
-    h.found = 0;
-    h.any_goal = 0;
-    h.n_overlay = 0;
-    h.n_neg = 0;
-    h.pad = 0;
-    v.hdr[e] = h;
-    v.overlay_count[v.cur_overlay][e] = 0;
-}
-
 __device__ inline int wave_min(int x) {
     for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
     return x;
@@ -41,6 +23,34 @@ __device__ inline int wave_max(int x) {
 __device__ inline unsigned wave_minu(unsigned x) {
     for (int o = 32; o > 0; o >>= 1) x = min(x, (unsigned)__shfl_xor((int)x, o));
     return x;
+}
+
+// Correctly rounded a / b for a divisor known in advance (rb = RN(1/b) from the host).  Two
+// fused steps give a candidate q; the exact residual r = a - b*q then PROVES that q is the
+// nearest double (|r| strictly below half an ulp of q times |b|, q not a power of two), in
+// which case q equals the IEEE quotient; any other case runs the hardware division.
+__device__ inline double div_known(double a, double b, double rb) {
+    const double q0 = a * rb;
+    if (a == 0.0) return q0;   // signed zero, as a / b gives
+    const double q = __builtin_fma(__builtin_fma(-b, q0, a), rb, q0);
+    const double r = __builtin_fma(-b, q, a);
+    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(long long, q);
+    const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+    const bool plain = ex > 60u && ex < 0x7FEu && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
+    const double half_ulp = __builtin_bit_cast(double, (long long)((unsigned long long)(ex - 53u) << 52));
+    if (plain && fabs(r) < half_ulp * fabs(b) * 0.999) return q;
+    return a / b;
+}
+
+// floor(RN(d / p)) for a divisor known in advance: d * RN(1/p) is within 3.4e-16 relative of
+// the rounded quotient, so away from the integers (guard band 1e-7, |q| < 2^24) both floors
+// agree; inside the band the quotient is recomputed with the hardware division.
+__device__ inline double floor_div_known(double d, double p, double rp) {
+    const double qf = d * rp;
+    const double fl = floor(qf);
+    const double frac = qf - fl;
+    if (fabs(qf) < 16777216.0 && frac > 1.0e-7 && frac < 1.0 - 1.0e-7) return fl;
+    return floor(d / p);
 }
 
 // One thread = 4 horizontally adjacent pixels (W % 4 == 0 is checked on the host).
@@ -76,14 +86,14 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             double x = 0.0, y = 0.0, z = 0.0;
             if (ok) {
                 z = (double)dk;
-                x = z * ((double)(c0 + k) - half_w) / v.fx;
-                y = z * yr / v.fy;
+                x = div_known(z * ((double)(c0 + k) - half_w), v.fx, v.inv_fx);
+                y = div_known(z * yr, v.fy, v.inv_fy);
             }
             const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
             const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
             const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
-            const double fr = floor((wz - mp.lower[2]) / v.p2m);
-            const double fc = floor((wx - mp.lower[0]) / v.p2m);
+            const double fr = floor_div_known(wz - mp.lower[2], v.p2m, v.inv_p2m);
+            const double fc = floor_div_known(wx - mp.lower[0], v.p2m, v.inv_p2m);
             uint32_t id = kDeadCell;
             unsigned long long key = 0;
             // comparisons in double so that huge or non-finite coordinates never reach a cast
@@ -133,13 +143,60 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             min_inv = min(min_inv, (unsigned)s_red[w][4]);
             err |= (unsigned)s_red[w][5];
         }
-        FrameHeader *h = v.hdr + e;
-        if (rmin <= rmax) {
-            atomicMin(&h->rmin, rmin); atomicMax(&h->rmax, rmax);
-            atomicMin(&h->cmin, cmin); atomicMax(&h->cmax, cmax);
+        // per-block partial; k_frame_header folds them (hundreds of blocks hammering one header
+        // line with atomics serialise at the memory side)
+        int *part = v.geo_part + ((int64_t)e * gridDim.x + blockIdx.x) * 8;
+        *reinterpret_cast<int4 *>(part) = make_int4(rmin, rmax, cmin, cmax);
+        *reinterpret_cast<int4 *>(part + 4) = make_int4((int)min_inv, (int)err, 0, 0);
+    }
+}
+
+// One block per env: folds the geometry blocks' partials into the frame header and resets the
+// per-step counters.
+__global__ __launch_bounds__(256) void k_frame_header(View v, int nblk) {
+    __shared__ int s_red[4][6];
+    const int e = blockIdx.x;
+    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
+    unsigned min_inv = kNoPixel, err = 0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        const int *part = v.geo_part + ((int64_t)e * nblk + b) * 8;
+        const int4 a = *reinterpret_cast<const int4 *>(part);
+        const int4 c = *reinterpret_cast<const int4 *>(part + 4);
+        rmin = min(rmin, a.x); rmax = max(rmax, a.y); cmin = min(cmin, a.z); cmax = max(cmax, a.w);
+        min_inv = min(min_inv, (unsigned)c.x);
+        err |= (unsigned)c.y;
+    }
+    rmin = wave_min(rmin); rmax = wave_max(rmax);
+    cmin = wave_min(cmin); cmax = wave_max(cmax);
+    min_inv = wave_minu(min_inv);
+    for (int o = 32; o > 0; o >>= 1) err |= (unsigned)__shfl_xor((int)err, o);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
+        s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
+            cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
+            min_inv = min(min_inv, (unsigned)s_red[w][4]);
+            err |= (unsigned)s_red[w][5];
         }
-        if (min_inv != kNoPixel) atomicMin(&h->min_invalid_pixel, min_inv);
-        if (err) atomicOr(&h->status, err);
+        FrameHeader h;
+        h.rmin = rmin; h.rmax = rmax; h.cmin = cmin; h.cmax = cmax;
+        h.wrmin = h.wcmin = 0x7FFFFFFF;
+        h.wrmax = h.wcmax = (int32_t)0x80000000;
+        h.min_invalid_pixel = min_inv;
+        h.n_winners = 0;
+        h.status = err;
+        h.found = 0;
+        h.any_goal = 0;
+        h.n_overlay = 0;
+        h.n_neg = 0;
+        h.pad = 0;
+        v.hdr[e] = h;
+        v.overlay_count[v.cur_overlay][e] = 0;
     }
 }
 
@@ -295,7 +352,7 @@ template <bool RUNS>
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
     __shared__ unsigned long long table_h[kSlots];
     __shared__ unsigned int table_i[kSlots];
-    __shared__ unsigned int s_base;
+    __shared__ unsigned int s_base, s_neg;
     __shared__ unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
 
     const int e = blockIdx.y;
@@ -343,7 +400,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     const uint4 *recs = v.rec + fbase;
     const unsigned int *part_start = v.part_start + e * (kMaxParts + 1);
     constexpr int kRunBatch = 4;
+    constexpr int kKeep = RUNS ? 14 : 1;   // records per thread kept in registers between the phases
+    uint4 keep[kKeep];
     int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
+    if (threadIdx.x == 0) s_neg = 0;
 
     for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
         const unsigned rec_beg = RUNS ? part_start[p] : 0u, rec_end = RUNS ? part_start[p + 1] : 0u;
@@ -355,7 +415,17 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
 
         // phase a
         if (RUNS) {
-            for (unsigned t0 = rec_beg + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
+            // the first kKeep records of every thread stay in registers for phase b
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u) {
+                const unsigned t = rec_beg + threadIdx.x + u * kWinnerThreads;
+                if (t < rec_end) keep[u] = recs[t];
+            }
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u)
+                if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end)
+                    atomicMax(&table_h[keep[u].y], ((unsigned long long)keep[u].w << 32) | keep[u].z);
+            for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
                 uint4 rec[kRunBatch];
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u) {
@@ -390,7 +460,12 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
         }
         __syncthreads();
         if (RUNS) {
-            for (unsigned t0 = rec_beg + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
+#pragma unroll
+            for (int u = 0; u < kKeep; ++u)
+                if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end &&
+                    table_h[keep[u].y] == (((unsigned long long)keep[u].w << 32) | keep[u].z))
+                    atomicMin(&table_i[keep[u].y], keep[u].x);
+            for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
                 uint4 rec[kRunBatch];
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u) {
@@ -447,8 +522,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             const int s = it * kWinnerThreads + threadIdx.x;
             if (!((balls[it] >> lane) & 1ull)) continue;
             const unsigned w = table_i[s];
-            const long long L = RUNS ? join_cell(p, s, nparts) : ((long long)p << kSlotShift) + s;
-            const int row = (int)(L / bw) + rmin, col = (int)(L % bw) + cmin;
+            // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
+            const unsigned L = RUNS ? (unsigned)join_cell(p, s, nparts) : ((unsigned)p << kSlotShift) + (unsigned)s;
+            const unsigned lrow = L / (unsigned)bw;
+            const int row = (int)lrow + rmin, col = (int)(L - lrow * (unsigned)bw) + cmin;
             lrmin = min(lrmin, row); lrmax = max(lrmax, row);
             lcmin = min(lcmin, col); lcmax = max(lcmax, col);
             // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
@@ -466,16 +543,31 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
                 v.wheight[fbase + pos] = table_h[s];
             }
         }
-        if (n_neg) atomicAdd(&hdr->n_neg, n_neg);
+        if (n_neg) atomicAdd(&s_neg, n_neg);
         __syncthreads();
     }
 
     // bbox of the update cells (goal_decay works on it, mapper.py:1117-1118)
     lrmin = wave_min(lrmin); lrmax = wave_max(lrmax);
     lcmin = wave_min(lcmin); lcmax = wave_max(lcmax);
-    if ((threadIdx.x & 63) == 0 && lrmin <= lrmax) {
-        atomicMin(&hdr->wrmin, lrmin); atomicMax(&hdr->wrmax, lrmax);
-        atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
+    // one set of header atomics per block (same-line atomics serialise at the memory side)
+    __syncthreads();
+    if (threadIdx.x == 0 && s_neg) atomicAdd(&hdr->n_neg, s_neg);
+    __shared__ int s_box[kWinnerThreads / 64][4];
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s_box[w][0] = lrmin; s_box[w][1] = lrmax; s_box[w][2] = lcmin; s_box[w][3] = lcmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWinnerThreads / 64; ++w) {
+            lrmin = min(lrmin, s_box[w][0]); lrmax = max(lrmax, s_box[w][1]);
+            lcmin = min(lcmin, s_box[w][2]); lcmax = max(lcmax, s_box[w][3]);
+        }
+        if (lrmin <= lrmax) {
+            atomicMin(&hdr->wrmin, lrmin); atomicMax(&hdr->wrmax, lrmax);
+            atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
+        }
     }
 }
 
@@ -517,14 +609,12 @@ void launch_resolve_wrapped(const View &v, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_wrapped, dim3(v.E), dim3(1024), 0, s, v, prob_rule ? 1 : 0);
 }
 
-void launch_begin_step(const View &v, hipStream_t s) {
-    hipLaunchKernelGGL(k_begin_step, dim3((v.E + 63) / 64), dim3(64), 0, s, v);
-}
 
 void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
     hipLaunchKernelGGL(k_geometry, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
+    hipLaunchKernelGGL(k_frame_header, dim3(v.E), dim3(256), 0, s, v, (int)grid.x);
 }
 
 void launch_winners(const View &v, hipStream_t s) {

@@ -62,12 +62,14 @@ struct View {
     int32_t E, H, W, N, C, n_schema, rule, use_height;
     float depth_min, depth_max;
     double fx, fy, p2m;
+    double inv_fx, inv_fy, inv_p2m;   // correctly rounded reciprocals (host division)
     // scratch (device)
     const EnvState *envs;
     const PoseBlock *poses;
     FrameHeader *hdr;
     uint32_t *cellid;          // [E][N]
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
+    int32_t *geo_part;         // [E][N/1024][8] per-geometry-block bbox / invalid pixel / error partials
     uint4 *rec;                // [E][N] binned pixel records (k_bin)
     unsigned int *bin_cnt;     // [E][N/1024][kMaxParts] per-block table counts, then record bases
     unsigned int *part_start;  // [E][kMaxParts+1] first record of each table
@@ -105,7 +107,6 @@ __host__ __device__ inline double unorder_f64(unsigned long long k) {
 }
 
 // launchers (defined in the .hip files)
-void launch_begin_step(const View &v, hipStream_t s);
 void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_winners(const View &v, hipStream_t s);
 void launch_resolve_wrapped(const View &v, hipStream_t s);

@@ -225,7 +225,7 @@ __device__ inline long long join_cell(int part, int slot, int nparts) {
     const long long chunk = (long long)(slot >> kInterleaveShift) * nparts + part;
     return (chunk << kInterleaveShift) | (slot & (kInterleave - 1));
 }
-__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
+__device__ inline BinFrame bin_frame(const FrameHeader *hdr, int min_parts) {
     BinFrame f;
     f.on = false;
     const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
@@ -234,7 +234,9 @@ __device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
     const long long ncell = (long long)f.bw * (long long)(rmax - rmin + 1);
     const long long np = (ncell + kSlots - 1) >> kSlotShift;
     if (np > kMaxParts) return f;
-    f.nparts = (int)np;
+    // at least min_parts tables per frame so that a small cell box still spreads its pixels
+    // over enough workgroups
+    f.nparts = max((int)np, min_parts);
     f.rmin_b = rmin + kCoordBias;
     f.cmin_b = cmin + kCoordBias;
     f.on = true;
@@ -249,7 +251,7 @@ __device__ inline int bin_cell(const BinFrame &f, uint32_t id) {
 __global__ __launch_bounds__(256) void k_bin_count(View v) {
     __shared__ unsigned int cnt[kMaxParts];
     const int e = blockIdx.y;
-    const BinFrame f = bin_frame(v.hdr + e);
+    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
     if (!f.on) return;
     if (threadIdx.x < kMaxParts) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void k_bin_count(View v) {
 __global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
     __shared__ unsigned int total[kMaxParts + 1];
     const int e = blockIdx.x;
-    const BinFrame f = bin_frame(v.hdr + e);
+    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
     if (!f.on) return;
     unsigned int *cnt = v.bin_cnt + (int64_t)e * kMaxParts * nbin;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
     __shared__ unsigned int base[kMaxParts];
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
-    const BinFrame f = bin_frame(v.hdr + e);
+    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
     if (!f.on) return;
     if (threadIdx.x < kMaxParts) {
         cnt[threadIdx.x] = 0;
@@ -365,11 +367,12 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     const int Hm = mp.map_h, Wm = mp.map_w;
     const int bw = cmax - cmin + 1;
     const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
-    const int nparts = (int)((ncell + kSlots - 1) >> kSlotShift);
+    const int nfull = (int)((ncell + kSlots - 1) >> kSlotShift);
     const int rmin_b = rmin + kCoordBias, cmin_b = cmin + kCoordBias;
-    // frames whose cell box needs at most kMaxParts tables are binned (k_bin) and read as runs;
-    // larger boxes fall back to scanning every cell id once per table
-    if (RUNS != (nparts <= kMaxParts)) return;
+    // frames whose cell box needs at most kMaxParts tables are binned (k_bin_*) and read as
+    // contiguous record ranges; larger boxes fall back to scanning every cell id once per table
+    if (RUNS != (nfull <= kMaxParts)) return;
+    const int nparts = RUNS ? max(nfull, v.min_parts) : nfull;
 
     // the cell all invalid-depth pixels fall into (they sit at the camera position,
     // mapper.py:28-31) and their common height

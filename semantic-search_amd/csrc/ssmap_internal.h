@@ -84,6 +84,7 @@ struct View {
     uint8_t *local_eroded;     // goal_decay: same shape
     int32_t *overlay[2];       // hv: [E][N] cells showing the goal overlay (prev / current)
     uint32_t *overlay_count[2];// [E]
+    int32_t min_parts;         // winner tables per frame at least (<= kWinnerPartsPerEnv)
     int32_t cur_overlay;       // which of the two lists is written this step
     int64_t local_stride;      // bytes per env in local_ids
     const int32_t *lut;        // [C] model class -> schema id

@@ -2,6 +2,7 @@
 // preparation (mapper.py:290-301) and kernel sequencing.  No torch types, no exceptions
 // across the boundary.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -300,6 +301,8 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
         return fail(SSMAP_ERR_INVALID_ARG, "gt_map and unc_map are required in probabilistic mode");
     if (r >= SSMAP_RULE_AVG_PROB && r <= SSMAP_RULE_LOG_ODDS && !maps->prob_map)
         return fail(SSMAP_ERR_INVALID_ARG, "prob_map is required for this rule");
+    if (maps->prob_map && reinterpret_cast<uintptr_t>(maps->prob_map) % 16)
+        return fail(SSMAP_ERR_INVALID_ARG, "prob_map must be 16-byte aligned (cell rows move as vectors)");
     if (r >= SSMAP_RULE_AVG_PROB && r <= SSMAP_RULE_W2_AVG_PROB && !maps->weight_map)
         return fail(SSMAP_ERR_INVALID_ARG, "weight_map is required for this rule");
     if (r == SSMAP_RULE_GOAL_DECAY && !maps->goal_map)

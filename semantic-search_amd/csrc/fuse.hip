@@ -83,66 +83,131 @@ __device__ inline void row_argmax(float &val, int &idx) {
 }
 
 // ---------------------------------------------------------------- register kernel
-template <int CT, int MODE>
+// Winner rows leave the block through LDS: the few pixels of a block that own a map cell park
+// their C probabilities in a staging row, then all threads write the staged rows to the
+// compact buffer with consecutive lanes on consecutive addresses (a winner writing its own
+// row would issue C stores of 4 scattered bytes per lane).
+template <int CT>
+struct Stage {
+    static constexpr int kRows = CT > 64 ? 32 : 64;
+    float row[kRows][CT];
+    int slot[kRows];
+    int count;
+};
+
+// PX consecutive pixels per thread: every class plane is read with one PX-dword load per lane.
+template <int CT, int MODE, int PX>
 __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
+    typedef float VecF __attribute__((ext_vector_type(PX)));
+    typedef int VecI __attribute__((ext_vector_type(PX)));
+    __shared__ Stage<CT> stage;
     const int e = blockIdx.y;
     const int t = threadIdx.x;
-    const int pix = blockIdx.x * kTile + t;
+    const int pix = (blockIdx.x * kTile + t) * PX;     // N is a multiple of PX (checked by the host)
     const bool active = pix < v.N;
     const int64_t fbase = (int64_t)e * v.N;
     const float *src = a.in + ((int64_t)e * CT) * v.N + (active ? pix : 0);
 
-    float x[CT];
+    float x[PX][CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) x[c] = src[(int64_t)c * v.N];
-
+    for (int c = 0; c < CT; ++c) {
+        // read once, never again: keep the frame out of the way of the map lines in L2
+        const VecF q = __builtin_nontemporal_load(reinterpret_cast<const VecF *>(src + (int64_t)c * v.N));
+#pragma unroll
+        for (int p = 0; p < PX; ++p) x[p][c] = q[p];
+    }
     if (a.from_logits) {
-        float m = -INFINITY;
+        VecI sid_v;
+        VecF unc_v, conf_v;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { x[c] *= a.inv_t; m = fmaxf(m, x[c]); }
-        float s = 0.0f;
+        for (int p = 0; p < PX; ++p) {
+            float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { x[c] = __expf(x[c] - m); s += x[c]; }
-        const float inv_s = 1.0f / s;
-        float hsum = 0.0f, best = -1.0f;
-        int bi = 0;
+            for (int c = 0; c < CT; ++c) { x[p][c] *= a.inv_t; m = fmaxf(m, x[p][c]); }
+            float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            x[c] *= inv_s;
-            hsum += x[c] * __logf(x[c] + 1e-6f);
-            if (x[c] > best) { best = x[c]; bi = c; }
-        }
-        const int sid = v.lut[bi];
-        float conf = best;
-        if (!a.pool_trivial && sid >= 3 && sid <= 8) {
-            // probability mass of every model class mapped to this goal id (infer.py:109-118)
-            float acc = 0.0f;
-            bool any = false;
+            for (int c = 0; c < CT; ++c) { x[p][c] = __expf(x[p][c] - m); s += x[p][c]; }
+            const float inv_s = 1.0f / s;
+            float hsum = 0.0f, best = -1.0f;
+            int bi = 0;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const bool hit = v.lut[c] == sid;
-                acc += hit ? x[c] : 0.0f;
-                any |= hit;
+                x[p][c] *= inv_s;
+                hsum += x[p][c] * __logf(x[p][c] + 1e-6f);
+                if (x[p][c] > best) { best = x[p][c]; bi = c; }
             }
-            if (any) conf = acc;
+            const int sid = v.lut[bi];
+            float conf = best;
+            if (!a.pool_trivial && sid >= 3 && sid <= 8) {
+                // probability mass of every model class mapped to this goal id (infer.py:109-118)
+                float acc = 0.0f;
+                bool any = false;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const bool hit = v.lut[c] == sid;
+                    acc += hit ? x[p][c] : 0.0f;
+                    any |= hit;
+                }
+                if (any) conf = acc;
+            }
+            sid_v[p] = sid; unc_v[p] = -hsum / __logf((float)CT); conf_v[p] = conf;
         }
         if (active) {
-            if (a.sem_out) a.sem_out[fbase + pix] = sid;
-            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / __logf((float)CT);
-            if (a.maxp_out) a.maxp_out[fbase + pix] = conf;
+            if (a.sem_out) __builtin_nontemporal_store(sid_v, reinterpret_cast<VecI *>(a.sem_out + fbase + pix));
+            if (a.unc_out) __builtin_nontemporal_store(unc_v, reinterpret_cast<VecF *>(a.unc_out + fbase + pix));
+            if (a.maxp_out) __builtin_nontemporal_store(conf_v, reinterpret_cast<VecF *>(a.maxp_out + fbase + pix));
             if (a.probs_out) {
                 float *dst = a.probs_out + ((int64_t)e * CT) * v.N + pix;
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dst[(int64_t)c * v.N] = x[c];
+                for (int c = 0; c < CT; ++c) {
+                    VecF q;
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) q[p] = x[p][c];
+                    *reinterpret_cast<VecF *>(dst + (int64_t)c * v.N) = q;
+                }
             }
         }
     }
     if (MODE == 0) return;
-    const int slot = active ? v.target[fbase + pix] : -1;
-    if (slot >= 0) {
-        float *dst = v.wprob + (fbase + slot) * CT;
+
+    VecI slot_v = -1;
+    if (active) slot_v = *reinterpret_cast<const VecI *>(v.target + fbase + pix);
+    if (t == 0) stage.count = 0;
+    __syncthreads();
+    int place[PX];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) dst[c] = x[c];
+    for (int p = 0; p < PX; ++p) {
+        place[p] = slot_v[p] >= 0 ? atomicAdd(&stage.count, 1) : -1;
+    }
+    __syncthreads();
+    const int total = stage.count;
+    constexpr int kRows = Stage<CT>::kRows;
+    for (int r0 = 0; r0 < total; r0 += kRows) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int k = place[p] - r0;
+            if (place[p] >= 0 && k >= 0 && k < kRows) {
+                stage.slot[k] = slot_v[p];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) stage.row[k][c] = x[p][c];
+            }
+        }
+        __syncthreads();
+        const int rows = min(kRows, total - r0);
+        if (CT % 4 == 0) {
+            constexpr int Q = CT / 4;
+            for (int j = t; j < rows * Q; j += kTile) {
+                const int k = j / Q, q = j - k * Q;
+                const float4 val = *reinterpret_cast<const float4 *>(&stage.row[k][4 * q]);
+                *reinterpret_cast<float4 *>(v.wprob + (fbase + stage.slot[k]) * CT + 4 * q) = val;
+            }
+        } else {
+            for (int j = t; j < rows * CT; j += kTile) {
+                const int k = j / CT, c = j - k * CT;
+                v.wprob[(fbase + stage.slot[k]) * CT + c] = stage.row[k][c];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -217,16 +282,22 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
 }
 
 // ---------------------------------------------------------------- rule update
-// Stage 4 for the probability rules.  A wave works on four update cells at a time, one per
-// 16-lane row; lane `sub` of a row owns classes sub, sub+16, ... (CPL per lane), so every
-// load / store of a cell's C contiguous floats is 64 contiguous bytes per row and the
-// per-cell sums and argmax are 16-lane DPP reductions.  List slots are in row-major cell
-// order, so the four rows of a wave (and the waves of a block) touch neighbouring cells.
+// Stage 4 for the probability rules.  A block takes 64 consecutive list slots per pass.
+//   rows: a wave works on four update cells at a time, one per 16-lane row; lane `sub` of a
+//         row owns the classes V*(sub+16k) .. +V-1 (k < K), so a cell's C contiguous floats
+//         move with K vector loads / stores per row and the per-cell sums and argmax are
+//         16-lane DPP reductions.
+//   side: the per-cell scalars (height, weight, uncertainty, label, colour, ground truth) are
+//         handled with lane <-> list slot, one array per wave: list slots are in cell order,
+//         so these are mostly consecutive addresses instead of four lanes per instruction.
 // MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
-template <int MODE, int CPL>
+template <int MODE, int V, int K>
 __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__restrict__ gt) {
-    constexpr int NB = 2;                       // row-batches in flight per wave
-    constexpr unsigned kRun = 4 * 4 * NB * 2;   // list slots per block pass
+    typedef float VecF __attribute__((ext_vector_type(V)));
+    constexpr int NB = 2;             // row-batches in flight per wave
+    constexpr unsigned kRun = 64;     // list slots per block pass
+    __shared__ int s_bi[kRun];
+    __shared__ float s_wn[kRun], s_ent[kRun];
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
     const unsigned n = v.hdr[e].n_winners;
@@ -237,123 +308,170 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     const float log_c = logf((float)C);
     const int lane = threadIdx.x & 63, sub = lane & 15, row = lane >> 4;
     const unsigned wave = threadIdx.x >> 6;
-    for (unsigned r0 = blockIdx.x * kRun; r0 < n; r0 += gridDim.x * kRun)
-    for (unsigned i0 = r0 + wave * 4 * NB; i0 < min(n, r0 + kRun); i0 += 16 * NB) {
-        float p[NB][CPL], mv[NB][CPL], h_old[NB], w_old[NB], p_first[NB];
-        unsigned long long hk[NB];
-        int cell[NB], gtv[NB];
-        bool live[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const unsigned i = i0 + 4 * b + row;
-            const int2 pc = i < n ? list[i] : make_int2((int)kLostBit, 0);
-            live[b] = !((uint32_t)pc.x & kLostBit);
-            cell[b] = pc.y;
-            if (live[b]) {
-                const float *mrow = mp.prob_map + (int64_t)cell[b] * C;
-                const float *prow = v.wprob + (fbase + i) * C;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = sub + 16 * k;
-                    mv[b][k] = c < C ? mrow[c] : 0.0f;
-                    p[b][k] = c < C ? prow[c] : 0.0f;
-                }
-                h_old[b] = mp.height_map[cell[b]];
-                hk[b] = v.wheight[fbase + i];
-                w_old[b] = MODE == 1 ? mp.weight_map[cell[b]] : 0.0f;
-                p_first[b] = MODE == 2 ? prow[0] : 0.0f;
-                gtv[b] = gt ? gt[fbase + (int)((uint32_t)pc.x & kPixMask)] : 0;
-            }
+    for (unsigned r0 = blockIdx.x * kRun; r0 < n; r0 += gridDim.x * kRun) {
+        // ---- side data of list slot r0 + lane (every wave: the new height feeds its stores)
+        const unsigned is = r0 + lane;
+        const int2 ps = is < n ? list[is] : make_int2((int)kLostBit, 0);
+        const bool side_live = !((uint32_t)ps.x & kLostBit);
+        float hnew = 0.0f;
+        int gtv = 0;
+        if (side_live) {
+            const float h_old = mp.height_map[ps.y];
+            hnew = fmaxf(h_old, (float)(unorder_f64(v.wheight[fbase + is]) - agent_y));
+            if (gt && wave == 1) gtv = gt[fbase + (int)((uint32_t)ps.x & kPixMask)];
         }
+        // ---- rows
+#pragma unroll 1
+        for (unsigned b0 = 0; b0 < 4; b0 += NB) {
+            VecF p[NB][K], mv[NB][K];
+            float w_old[NB];
+            int cell[NB];
+            bool live[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            // rows without a live cell still take part in the (row-local) DPP steps
-            float *mrow = mp.prob_map + (int64_t)cell[b] * C;
-            const bool on = live[b];
-            float best = -INFINITY;
-            int bi = 0x7FFFFFFF;
-            float ent_out = 0.0f, wn = 0.0f;
-            if (MODE == 1) {
-                float wgt = 1.0f;
-                if (v.rule != SSMAP_RULE_AVG_PROB) {
-                    float sp = 0.0f;
+            for (int b = 0; b < NB; ++b) {
+                const unsigned i = r0 + 16 * wave + 4 * (b0 + b) + row;
+                const int2 pc = i < n ? list[i] : make_int2((int)kLostBit, 0);
+                live[b] = !((uint32_t)pc.x & kLostBit);
+                cell[b] = pc.y;
+                w_old[b] = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) sp += on ? p[b][k] : 0.0f;
-                    sp = row_sum(sp);
+                for (int k = 0; k < K; ++k) { mv[b][k] = 0.0f; p[b][k] = 0.0f; }
+                if (live[b]) {
+                    const float *mrow = mp.prob_map + (int64_t)cell[b] * C;
+                    const float *prow = v.wprob + (fbase + i) * C;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int c = V * (sub + 16 * k);
+                        if (c < C) {
+                            mv[b][k] = *reinterpret_cast<const VecF *>(mrow + c);
+                            p[b][k] = *reinterpret_cast<const VecF *>(prow + c);
+                        }
+                    }
+                    if (MODE == 1) w_old[b] = mp.weight_map[cell[b]];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                // rows without a live cell still take part in the (row-local) DPP steps
+                float *mrow = mp.prob_map + (int64_t)cell[b] * C;
+                const bool on = live[b];
+                float best = -INFINITY;
+                int bi = 0x7FFFFFFF;
+                float ent_out = 0.0f, wn = 0.0f;
+                if (MODE == 1) {
+                    float wgt = 1.0f;
+                    if (v.rule != SSMAP_RULE_AVG_PROB) {
+                        float sp = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+#pragma unroll
+                            for (int j = 0; j < V; ++j) sp += p[b][k][j];
+                        sp = row_sum(sp);
+                        float hs = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+#pragma unroll
+                            for (int j = 0; j < V; ++j) hs += (on && V * (sub + 16 * k) < C) ? entr(p[b][k][j] / sp) : 0.0f;
+                        const float ent = row_sum(hs) / log_c;
+                        wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
+                    }
+                    wn = w_old[b] + wgt;
+                    const float rcp = 1.0f / wn;
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int c = V * (sub + 16 * k);
+                        if (on && c < C) {
+#pragma unroll
+                            for (int j = 0; j < V; ++j) {
+                                const float d = rcp * (p[b][k][j] - mv[b][k][j]);
+                                mv[b][k][j] = mv[b][k][j] + d * wgt;
+                                sm += mv[b][k][j];
+                            }
+                            *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];
+                        }
+                    }
+                    sm = row_sum(sm);
                     float hs = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) hs += (on && sub + 16 * k < C) ? entr(p[b][k] / sp) : 0.0f;
-                    const float ent = row_sum(hs) / log_c;
-                    wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
-                }
-                wn = w_old[b] + wgt;
-                const float rcp = 1.0f / wn;
-                float sm = 0.0f;
+                    for (int k = 0; k < K; ++k) {
+                        const int c = V * (sub + 16 * k);
+                        if (on && c < C) {
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = sub + 16 * k;
-                    if (on && c < C) {
-                        const float d = rcp * (p[b][k] - mv[b][k]);
-                        mv[b][k] = mv[b][k] + d * wgt;
-                        mrow[c] = mv[b][k];
-                        sm += mv[b][k];
+                            for (int j = 0; j < V; ++j) {
+                                hs += entr(mv[b][k][j] / sm);
+                                if (arg_better(mv[b][k][j], c + j, best, bi)) { best = mv[b][k][j]; bi = c + j; }
+                            }
+                        }
+                    }
+                    ent_out = row_sum(hs) / log_c;
+                } else {
+                    // class 0 of the observation, broadcast over the row (the other lanes add zeros)
+                    const float p0 = row_sum(sub == 0 ? p[b][0][0] : 0.0f);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int c = V * (sub + 16 * k);
+                        if (on && c < C) {
+#pragma unroll
+                            for (int j = 0; j < V; ++j) {
+                                mv[b][k][j] = mv[b][k][j] + __logf(p[b][k][j] / p0);
+                                if (arg_better(mv[b][k][j], c + j, best, bi)) { best = mv[b][k][j]; bi = c + j; }
+                            }
+                            *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];
+                        }
                     }
                 }
-                sm = row_sum(sm);
-                float hs = 0.0f;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = sub + 16 * k;
-                    if (on && c < C) {
-                        hs += entr(mv[b][k] / sm);
-                        if (arg_better(mv[b][k], c, best, bi)) { best = mv[b][k]; bi = c; }
-                    }
+                row_argmax(best, bi);
+                if (sub == 0) {
+                    const unsigned j = 16 * wave + 4 * (b0 + b) + row;
+                    s_bi[j] = bi;
+                    if (MODE == 1) { s_wn[j] = wn; s_ent[j] = ent_out; }
                 }
-                ent_out = row_sum(hs) / log_c;
-            } else {
-                const float p0 = p_first[b];
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = sub + 16 * k;
-                    if (on && c < C) {
-                        mv[b][k] = mv[b][k] + __logf(p[b][k] / p0);
-                        mrow[c] = mv[b][k];
-                        if (arg_better(mv[b][k], c, best, bi)) { best = mv[b][k]; bi = c; }
-                    }
-                }
-            }
-            row_argmax(best, bi);
-            if (on && sub == 0) {
-                // height map and ground-truth map (mapper.py:338-341, 361-363)
-                const float hnew = fmaxf(h_old[b], (float)(unorder_f64(hk[b]) - agent_y));
-                mp.height_map[cell[b]] = hnew;
-                if (gt) mp.gt_map[cell[b]] = (uint32_t)gtv[b];
-                if (MODE == 1) {
-                    mp.weight_map[cell[b]] = wn;
-                    mp.unc_map[cell[b]] = ent_out;
-                }
-                const int id = occupancy_override(v.lut[bi], hnew, v.use_height, v.n_schema);
-                commit_cell(mp, v.palette, cell[b], id);
             }
         }
+        __syncthreads();
+        // ---- side stores: height map and ground-truth map (mapper.py:338-341, 361-363), label, colour
+        if (side_live) {
+            const int cell = ps.y;
+            const int id = occupancy_override(v.lut[s_bi[lane]], hnew, v.use_height, v.n_schema);
+            if (wave == 0) {
+                mp.height_map[cell] = hnew;
+                if (MODE == 1) mp.weight_map[cell] = s_wn[lane];
+            } else if (wave == 1) {
+                if (gt) mp.gt_map[cell] = (uint32_t)gtv;
+                if (MODE == 1) mp.unc_map[cell] = s_ent[lane];
+            } else if (wave == 2) {
+                mp.semantic_map[cell] = (uint32_t)id;
+            } else {
+                const uint8_t *rgb = v.palette + 3 * id;
+                uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+                dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+            }
+        }
+        __syncthreads();
     }
 }
 
-template <int CT>
-static void launch_reg(int mode, dim3 grid, hipStream_t s, const View &v, const StreamArgs &a) {
-    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kTile), 0, s, v, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kTile), 0, s, v, a);
-    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kTile), 0, s, v, a);
+template <int CT, int PX>
+static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
+    dim3 grid((v.N / PX + kTile - 1) / kTile, v.E);
+    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, PX>), grid, dim3(kTile), 0, s, v, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, PX>), grid, dim3(kTile), 0, s, v, a);
+    else hipLaunchKernelGGL((k_stream_reg<CT, 2, PX>), grid, dim3(kTile), 0, s, v, a);
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
     dim3 grid(256, v.E), block(256);
     const bool lo = v.rule == SSMAP_RULE_LOG_ODDS;
-    const int cpl = (v.C + 15) / 16;
-#define GO(MODE, CPL) hipLaunchKernelGGL((k_update_prob<MODE, CPL>), grid, block, 0, s, v, f.semantic_gt)
-    if (cpl <= 3) { if (lo) GO(2, 3); else GO(1, 3); }
-    else if (cpl <= 4) { if (lo) GO(2, 4); else GO(1, 4); }
-    else { if (lo) GO(2, 10); else GO(1, 10); }
+    // widest vector that divides C (every cell row and staged row then starts on a vector boundary;
+    // engine scratch is 256-byte aligned, bound maps are checked when they are bound)
+    const int vec = v.C % 4 == 0 ? 4 : (v.C % 2 == 0 ? 2 : 1);
+    const int k = (v.C + 16 * vec - 1) / (16 * vec);
+#define GO(V, K) do { if (lo) hipLaunchKernelGGL((k_update_prob<2, V, K>), grid, block, 0, s, v, f.semantic_gt); \
+                      else hipLaunchKernelGGL((k_update_prob<1, V, K>), grid, block, 0, s, v, f.semantic_gt); } while (0)
+    if (vec == 4) { if (k <= 1) GO(4, 1); else GO(4, 3); }
+    else if (vec == 2) { if (k <= 2) GO(2, 2); else GO(2, 5); }
+    else { if (k <= 3) GO(1, 3); else GO(1, 10); }
 #undef GO
 }
 
@@ -368,15 +486,17 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
     a.maxp_out = f.semantic_max_prob;
     a.probs_out = probs_out;
     a.gt = f.semantic_gt;
-    dim3 grid((v.N + kTile - 1) / kTile, v.E);
     int mode = 0;
     if (fuse) mode = v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1;
+    // One pixel per thread: wider per-lane loads (2 or 4 pixels) measured slower on gfx950 because
+    // the larger register footprint costs more occupancy than the wider requests gain.
     switch (v.C) {
-        case 37: launch_reg<37>(mode, grid, s, v, a); return;
-        case 40: launch_reg<40>(mode, grid, s, v, a); return;
-        case 150: launch_reg<150>(mode, grid, s, v, a); return;
+        case 37: launch_reg<37, 1>(mode, s, v, a); return;
+        case 40: launch_reg<40, 1>(mode, s, v, a); return;
+        case 150: launch_reg<150, 1>(mode, s, v, a); return;
         default: break;
     }
+    dim3 grid((v.N + kTile - 1) / kTile, v.E);
     const size_t lds = (size_t)v.C * kStride * sizeof(float);
     auto go = [&](auto kern) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -95,102 +95,93 @@ struct Stage {
     int count;
 };
 
-// PX consecutive pixels per thread: every class plane is read with one PX-dword load per lane.
-template <int CT, int MODE, int PX>
+// One pixel per thread.  The C class planes of the env's frame are read through one buffer
+// descriptor: lane offset (pixel) in a vector register, plane offset in a scalar register, so
+// the C loads need no per-lane 64-bit address arithmetic.  Loads are nontemporal: the frame is
+// read once and should not push the map lines out of L2.  (Two or four pixels per thread with
+// wider loads measured slower: the larger register footprint costs more occupancy than the
+// wider requests gain.)
+template <int CT, int MODE>
 __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
-    typedef float VecF __attribute__((ext_vector_type(PX)));
-    typedef int VecI __attribute__((ext_vector_type(PX)));
     __shared__ Stage<CT> stage;
     const int e = blockIdx.y;
     const int t = threadIdx.x;
-    const int pix = (blockIdx.x * kTile + t) * PX;     // N is a multiple of PX (checked by the host)
+    const int pix = blockIdx.x * kTile + t;
     const bool active = pix < v.N;
     const int64_t fbase = (int64_t)e * v.N;
-    const float *src = a.in + ((int64_t)e * CT) * v.N + (active ? pix : 0);
+    const int boff = active ? pix * 4 : 0;
+    const int plane_bytes = v.N * 4;          // C * N * 4 < 2^31 is checked by the host
+    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
 
-    float x[PX][CT];
+    float x[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        // read once, never again: keep the frame out of the way of the map lines in L2
-        const VecF q = __builtin_nontemporal_load(reinterpret_cast<const VecF *>(src + (int64_t)c * v.N));
-#pragma unroll
-        for (int p = 0; p < PX; ++p) x[p][c] = q[p];
-    }
+    for (int c = 0; c < CT; ++c)
+        x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+
     if (a.from_logits) {
-        VecI sid_v;
-        VecF unc_v, conf_v;
+        // no implicit fused multiply-add in here: x k - max(x k) must be exactly 0 at the max
+#pragma clang fp contract(off)
+        // softmax(x / T) in base 2: exp(y - max y) = exp2(x k - max(x k)), k = log2(e) / T
+        const float k2 = a.inv_t * 1.44269504088896341f;
+        float m = -INFINITY;
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            float m = -INFINITY;
+        for (int c = 0; c < CT; ++c) { x[c] *= k2; m = fmaxf(m, x[c]); }
+        float s = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) { x[p][c] *= a.inv_t; m = fmaxf(m, x[p][c]); }
-            float s = 0.0f;
+        for (int c = 0; c < CT; ++c) { x[c] = __builtin_amdgcn_exp2f(x[c] - m); s += x[c]; }
+        const float inv_s = 1.0f / s;
+        // the class at the max has exp2(0) = 1, so the largest probability is inv_s itself;
+        // ties go to the lowest class index like argmax does
+        float hsum = 0.0f;
+        int bi = 0;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) { x[p][c] = __expf(x[p][c] - m); s += x[p][c]; }
-            const float inv_s = 1.0f / s;
-            float hsum = 0.0f, best = -1.0f;
-            int bi = 0;
+        for (int c = CT - 1; c >= 0; --c) {
+            x[c] *= inv_s;
+            hsum = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + 1e-6f), hsum);   // log2
+            bi = x[c] == inv_s ? c : bi;
+        }
+        const int sid = v.lut[bi];
+        float conf = inv_s;
+        if (!a.pool_trivial && sid >= 3 && sid <= 8) {
+            // probability mass of every model class mapped to this goal id (infer.py:109-118)
+            float acc = 0.0f;
+            bool any = false;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                x[p][c] *= inv_s;
-                hsum += x[p][c] * __logf(x[p][c] + 1e-6f);
-                if (x[p][c] > best) { best = x[p][c]; bi = c; }
+                const bool hit = v.lut[c] == sid;
+                acc += hit ? x[c] : 0.0f;
+                any |= hit;
             }
-            const int sid = v.lut[bi];
-            float conf = best;
-            if (!a.pool_trivial && sid >= 3 && sid <= 8) {
-                // probability mass of every model class mapped to this goal id (infer.py:109-118)
-                float acc = 0.0f;
-                bool any = false;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const bool hit = v.lut[c] == sid;
-                    acc += hit ? x[p][c] : 0.0f;
-                    any |= hit;
-                }
-                if (any) conf = acc;
-            }
-            sid_v[p] = sid; unc_v[p] = -hsum / __logf((float)CT); conf_v[p] = conf;
+            if (any) conf = acc;
         }
         if (active) {
-            if (a.sem_out) __builtin_nontemporal_store(sid_v, reinterpret_cast<VecI *>(a.sem_out + fbase + pix));
-            if (a.unc_out) __builtin_nontemporal_store(unc_v, reinterpret_cast<VecF *>(a.unc_out + fbase + pix));
-            if (a.maxp_out) __builtin_nontemporal_store(conf_v, reinterpret_cast<VecF *>(a.maxp_out + fbase + pix));
+            const float unc = hsum * (-0.693147180559945309f / __logf((float)CT));
+            if (a.sem_out) __builtin_nontemporal_store(sid, a.sem_out + fbase + pix);
+            if (a.unc_out) __builtin_nontemporal_store(unc, a.unc_out + fbase + pix);
+            if (a.maxp_out) __builtin_nontemporal_store(conf, a.maxp_out + fbase + pix);
             if (a.probs_out) {
                 float *dst = a.probs_out + ((int64_t)e * CT) * v.N + pix;
 #pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    VecF q;
-#pragma unroll
-                    for (int p = 0; p < PX; ++p) q[p] = x[p][c];
-                    *reinterpret_cast<VecF *>(dst + (int64_t)c * v.N) = q;
-                }
+                for (int c = 0; c < CT; ++c) dst[(int64_t)c * v.N] = x[c];
             }
         }
     }
     if (MODE == 0) return;
 
-    VecI slot_v = -1;
-    if (active) slot_v = *reinterpret_cast<const VecI *>(v.target + fbase + pix);
+    const int slot = active ? v.target[fbase + pix] : -1;
     if (t == 0) stage.count = 0;
     __syncthreads();
-    int place[PX];
-#pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        place[p] = slot_v[p] >= 0 ? atomicAdd(&stage.count, 1) : -1;
-    }
+    const int place = slot >= 0 ? atomicAdd(&stage.count, 1) : -1;
     __syncthreads();
     const int total = stage.count;
     constexpr int kRows = Stage<CT>::kRows;
     for (int r0 = 0; r0 < total; r0 += kRows) {
+        const int k = place - r0;
+        if (place >= 0 && k >= 0 && k < kRows) {
+            stage.slot[k] = slot;
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            const int k = place[p] - r0;
-            if (place[p] >= 0 && k >= 0 && k < kRows) {
-                stage.slot[k] = slot_v[p];
-#pragma unroll
-                for (int c = 0; c < CT; ++c) stage.row[k][c] = x[p][c];
-            }
+            for (int c = 0; c < CT; ++c) stage.row[k][c] = x[c];
         }
         __syncthreads();
         const int rows = min(kRows, total - r0);
@@ -452,12 +443,12 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     }
 }
 
-template <int CT, int PX>
+template <int CT>
 static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
-    dim3 grid((v.N / PX + kTile - 1) / kTile, v.E);
-    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, PX>), grid, dim3(kTile), 0, s, v, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, PX>), grid, dim3(kTile), 0, s, v, a);
-    else hipLaunchKernelGGL((k_stream_reg<CT, 2, PX>), grid, dim3(kTile), 0, s, v, a);
+    dim3 grid((v.N + kTile - 1) / kTile, v.E);
+    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kTile), 0, s, v, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kTile), 0, s, v, a);
+    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kTile), 0, s, v, a);
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
@@ -488,13 +479,14 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
     a.gt = f.semantic_gt;
     int mode = 0;
     if (fuse) mode = v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1;
-    // One pixel per thread: wider per-lane loads (2 or 4 pixels) measured slower on gfx950 because
-    // the larger register footprint costs more occupancy than the wider requests gain.
-    switch (v.C) {
-        case 37: launch_reg<37, 1>(mode, s, v, a); return;
-        case 40: launch_reg<40, 1>(mode, s, v, a); return;
-        case 150: launch_reg<150, 1>(mode, s, v, a); return;
-        default: break;
+    // the register kernels address a whole frame with 32-bit buffer offsets
+    if ((int64_t)v.C * v.N * 4 < (1ll << 31)) {
+        switch (v.C) {
+            case 37: launch_reg<37>(mode, s, v, a); return;
+            case 40: launch_reg<40>(mode, s, v, a); return;
+            case 150: launch_reg<150>(mode, s, v, a); return;
+            default: break;
+        }
     }
     dim3 grid((v.N + kTile - 1) / kTile, v.E);
     const size_t lds = (size_t)v.C * kStride * sizeof(float);

@@ -38,7 +38,8 @@ def _newer(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "ssmap_internal.h"), os.path.join(ROOT, "include", "ssmap.h")]
+    headers = [os.path.join(CSRC, "ssmap_internal.h"), os.path.join(CSRC, "rows.h"),
+               os.path.join(ROOT, "include", "ssmap.h")]
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs, procs = [], []

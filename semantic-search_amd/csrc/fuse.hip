@@ -12,19 +12,13 @@
 // to a wave, lanes over the classes: the read-modify-write of the cell's C contiguous floats
 // in the fused map is coalesced and the per-cell entropy / argmax are wavefront reductions.
 #include "ssmap_internal.h"
+#include "rows.h"
 
 namespace ssmap {
 
 constexpr int kTile = 256;
 constexpr int kStride = kTile + 1;
 
-// numpy argmax order: NaN beats everything, ties go to the lower index
-__device__ inline bool arg_better(float a, int ia, float b, int ib) {
-    const bool an = a != a, bn = b != b;
-    if (an != bn) return an;
-    if (an) return ia < ib;
-    return a > b || (a == b && ia < ib);
-}
 // scipy.special.entr: -x log x, 0 at 0, -inf below 0
 __device__ inline float entr(float x) {
     if (x > 0.0f) return -x * __logf(x);
@@ -56,31 +50,6 @@ struct StreamArgs {
     float *unc_out, *maxp_out, *probs_out;
     const int32_t *gt;
 };
-
-// ---- 16-lane row reductions with DPP rotates (no LDS traffic): after the four steps every
-// lane of a row holds the reduction over the row.
-template <int N>
-__device__ inline float row_ror(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xF, 0xF, false));
-}
-template <int N>
-__device__ inline int row_ror(int x) {
-    return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
-}
-__device__ inline float row_sum(float x) {
-    x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); x += row_ror<1>(x);
-    return x;
-}
-template <int N>
-__device__ inline void row_argmax_step(float &val, int &idx) {
-    const float ov = row_ror<N>(val);
-    const int oi = row_ror<N>(idx);
-    if (arg_better(ov, oi, val, idx)) { val = ov; idx = oi; }
-}
-__device__ inline void row_argmax(float &val, int &idx) {
-    row_argmax_step<8>(val, idx); row_argmax_step<4>(val, idx);
-    row_argmax_step<2>(val, idx); row_argmax_step<1>(val, idx);
-}
 
 // ---------------------------------------------------------------- register kernel
 // Winner rows leave the block through LDS: the few pixels of a block that own a map cell park

@@ -350,12 +350,21 @@ __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
 //   phase b   table_i[slot] = min pixel index among the pixels that reach that max
 //   phase c   slots whose winner passes the filters are appended to the update list
 // Integer max / min are order independent, so the result is deterministic.
+struct WinnerShared {
+    unsigned long long table_h[kSlots];
+    unsigned int table_i[kSlots];
+    unsigned int s_base, s_neg;
+    unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
+    int s_box[kWinnerThreads / 64][4];
+};
+
 template <bool RUNS>
-__global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
-    __shared__ unsigned long long table_h[kSlots];
-    __shared__ unsigned int table_i[kSlots];
-    __shared__ unsigned int s_base, s_neg;
-    __shared__ unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
+__device__ __forceinline__ void winners_body(const View &v, int write_target, int write_list, WinnerShared &sh) {
+    unsigned long long (&table_h)[kSlots] = sh.table_h;
+    unsigned int (&table_i)[kSlots] = sh.table_i;
+    unsigned int &s_base = sh.s_base, &s_neg = sh.s_neg;
+    unsigned int (&s_cnt)[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)] = sh.s_cnt;
+    int (&s_box)[kWinnerThreads / 64][4] = sh.s_box;
 
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
@@ -369,9 +378,6 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
     const int nfull = (int)((ncell + kSlots - 1) >> kSlotShift);
     const int rmin_b = rmin + kCoordBias, cmin_b = cmin + kCoordBias;
-    // frames whose cell box needs at most kMaxParts tables are binned (k_bin_*) and read as
-    // contiguous record ranges; larger boxes fall back to scanning every cell id once per table
-    if (RUNS != (nfull <= kMaxParts)) return;
     const int nparts = RUNS ? max(nfull, v.min_parts) : nfull;
 
     // the cell all invalid-depth pixels fall into (they sit at the camera position,
@@ -556,7 +562,6 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     // one set of header atomics per block (same-line atomics serialise at the memory side)
     __syncthreads();
     if (threadIdx.x == 0 && s_neg) atomicAdd(&hdr->n_neg, s_neg);
-    __shared__ int s_box[kWinnerThreads / 64][4];
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
         s_box[w][0] = lrmin; s_box[w][1] = lrmax; s_box[w][2] = lcmin; s_box[w][3] = lcmax;
@@ -572,6 +577,17 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
             atomicMin(&hdr->wcmin, lcmin); atomicMax(&hdr->wcmax, lcmax);
         }
     }
+}
+
+// Frames whose cell box needs at most kMaxParts tables are binned (k_bin_*) and read as
+// contiguous record ranges; larger boxes fall back to scanning every cell id once per table.
+__global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
+    __shared__ WinnerShared sh;
+    const FrameHeader *hdr = v.hdr + blockIdx.y;
+    const long long ncell = (long long)(hdr->cmax - hdr->cmin + 1) * (long long)(hdr->rmax - hdr->rmin + 1);
+    if (hdr->rmin > hdr->rmax) return;
+    if (((ncell + kSlots - 1) >> kSlotShift) <= kMaxParts) winners_body<true>(v, write_target, write_list, sh);
+    else winners_body<false>(v, write_target, write_list, sh);
 }
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
@@ -628,8 +644,7 @@ void launch_winners(const View &v, hipStream_t s) {
     hipLaunchKernelGGL(k_bin_count, grid_bin, dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_bin_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
     hipLaunchKernelGGL(k_bin_scatter, grid_bin, dim3(256), 0, s, v);
-    hipLaunchKernelGGL(k_winners<true>, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
-    hipLaunchKernelGGL(k_winners<false>, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
 }
 
 }  // namespace ssmap

@@ -7,6 +7,7 @@
 // Compiled with -ffp-contract=off (the view-distance gate is float64 and must round like
 // numpy's sqrt(dx*dx + dz*dz)).
 #include "ssmap_internal.h"
+#include "rows.h"
 
 namespace ssmap {
 
@@ -288,24 +289,20 @@ __global__ void k_gd_apply(View v, int dil) {
 
 // ---------------------------------------------------------------- stage 5
 // The filled disk of radius r around the robot cell (per-row half widths = the raster of
-// OpenCV's filled circle, mapper.py:737-743) is swept 64 cells at a time by each wave.  The
-// cheap per-cell tests run one cell per lane; for the probability rules the entropy of each
-// surviving goal cell is then computed by the whole wave, lanes over classes.
-constexpr int kFoundBlocks = 8;
+// OpenCV's filled circle, mapper.py:737-743) is swept 64 cells at a time by each wave, one
+// cell per lane for the cheap tests.  For the probability rules the surviving goal cells of
+// the block are collected in LDS and their entropies are then computed sixteen at a time,
+// one cell per 16-lane row with the lanes over the classes.
+constexpr int kFoundBlocks = 24;
+constexpr int kFoundThreads = 256;
 
-__device__ inline float wsum(float x) {
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
-__device__ inline float wmaxf(float x) {
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-    return x;
-}
 __device__ inline float entr_f(float x) {
     return x > 0.0f ? -x * logf(x) : (x == 0.0f ? 0.0f : (x != x ? x : -INFINITY));
 }
 
-__global__ __launch_bounds__(256) void k_found(View v) {
+__global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
+    __shared__ int s_cand[kFoundThreads];
+    __shared__ unsigned int s_n;
     const int e = blockIdx.y;
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
@@ -316,15 +313,15 @@ __global__ __launch_bounds__(256) void k_found(View v) {
     const bool avg = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_W2_AVG_PROB;
     const bool by_entropy = avg || v.rule == SSMAP_RULE_LOG_ODDS;
     const float log_c = C > 0 ? logf((float)C) : 1.0f;
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    const int n_chunks = (side * side + 63) >> 6;
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int row_id = threadIdx.x >> 4;                 // 16 rows of 16 lanes per block
+    const int n_cells = side * side;
     bool found = false;
-    for (int chunk = wave; chunk < n_chunks; chunk += n_waves) {
-        const int i = chunk * 64 + lane;
+    // every pass takes blockDim cells per block; the trip count is the same for all threads
+    for (int base = blockIdx.x * kFoundThreads; base < n_cells; base += gridDim.x * kFoundThreads) {
+        const int i = base + threadIdx.x;
         int cell = -1;
-        if (i < side * side) {
+        if (i < n_cells) {
             const int dr = i / side - R, dc = i % side - R;
             const int half = v.disk_hw[dr < 0 ? -dr : dr];
             const int row = pb.robot_row + dr, col = pb.robot_col + dc;
@@ -350,36 +347,44 @@ __global__ __launch_bounds__(256) void k_found(View v) {
             found |= cand;
             continue;
         }
-        unsigned long long todo = __ballot(cand);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int gcell = __shfl(cell, src);
-            const float *m = mp.prob_map + (int64_t)gcell * C;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const unsigned long long ball = __ballot(cand);
+        unsigned wbase = 0;
+        if (lane == 0 && ball) wbase = atomicAdd(&s_n, (unsigned)__popcll(ball));
+        wbase = __shfl(wbase, 0);
+        if (cand) s_cand[wbase + (unsigned)__popcll(ball & ((1ull << lane) - 1ull))] = cell;
+        __syncthreads();
+        const unsigned n_cand = s_n;
+        for (unsigned k0 = 0; k0 < n_cand; k0 += 16) {     // same trip count for the whole block
+            const unsigned k = k0 + row_id;
+            const bool on = k < n_cand;
+            const float *m = mp.prob_map + (int64_t)(on ? s_cand[k] : 0) * C;
             float ent;
             if (avg) {
                 float s = 0.0f;
-                for (int c = lane; c < C; c += 64) s += m[c];
-                s = wsum(s);
+                for (int c = sub; c < C; c += 16) s += on ? m[c] : 0.0f;
+                s = row_sum(s);
                 float hs = 0.0f;
-                for (int c = lane; c < C; c += 64) hs += entr_f(m[c] / s);
-                ent = wsum(hs) / log_c;
+                for (int c = sub; c < C; c += 16) hs += on ? entr_f(m[c] / s) : 0.0f;
+                ent = row_sum(hs) / log_c;
             } else {   // softmax of the log-odds first (mapper.py:805-812)
                 float mx = -INFINITY;
-                for (int c = lane; c < C; c += 64) mx = fmaxf(mx, m[c]);
-                mx = wmaxf(mx);
+                for (int c = sub; c < C; c += 16) mx = fmaxf(mx, on ? m[c] : 0.0f);
+                mx = row_max(mx);
                 float s = 0.0f;
-                for (int c = lane; c < C; c += 64) s += expf(m[c] - mx);
-                s = wsum(s);
+                for (int c = sub; c < C; c += 16) s += on ? expf(m[c] - mx) : 0.0f;
+                s = row_sum(s);
                 float s2 = 0.0f;
-                for (int c = lane; c < C; c += 64) s2 += expf(m[c] - mx) / s;
-                s2 = wsum(s2);
+                for (int c = sub; c < C; c += 16) s2 += on ? expf(m[c] - mx) / s : 0.0f;
+                s2 = row_sum(s2);
                 float hs = 0.0f;
-                for (int c = lane; c < C; c += 64) hs += entr_f((expf(m[c] - mx) / s) / s2);
-                ent = wsum(hs) / log_c;
+                for (int c = sub; c < C; c += 16) hs += on ? entr_f((expf(m[c] - mx) / s) / s2) : 0.0f;
+                ent = row_sum(hs) / log_c;
             }
-            if (ent < v.prm.entropy_threshold) found = true;
+            if (on && ent < v.prm.entropy_threshold) found = true;
         }
+        __syncthreads();
     }
     if (found) v.hdr[e].found = 1;
     // clear the wrapped-cell quadrant slots of this frame
@@ -408,7 +413,7 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
 }
 
 void launch_found(const View &v, hipStream_t s) {
-    hipLaunchKernelGGL(k_found, dim3(kFoundBlocks, v.E), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_found, dim3(kFoundBlocks, v.E), dim3(kFoundThreads), 0, s, v);
 }
 
 }  // namespace ssmap

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
 
+    // asked for first: the answer is needed last, after the softmax arithmetic
+    int slot = -1;
+    if (MODE != 0 && active) slot = __builtin_nontemporal_load(v.target + fbase + pix);
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -138,7 +141,6 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
     }
     if (MODE == 0) return;
 
-    const int slot = active ? v.target[fbase + pix] : -1;
     if (t == 0) stage.count = 0;
     __syncthreads();
     const int place = slot >= 0 ? atomicAdd(&stage.count, 1) : -1;

@@ -15,6 +15,7 @@ using namespace ssmap;
 
 namespace {
 
+constexpr int kPoseRing = 8;
 thread_local std::string g_error;
 
 int fail(int code, const std::string &msg) {
@@ -29,7 +30,6 @@ int fail(int code, const std::string &msg) {
             return fail(SSMAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__)); \
     } while (0)
 
-constexpr int kPoseRing = 8;
 
 struct Quat { double w, x, y, z; };
 
@@ -103,7 +103,8 @@ struct ssmap_engine {
     std::vector<EnvState> envs;        // host mirror
     EnvState *d_envs = nullptr;
     PoseBlock *d_poses = nullptr;
-    PoseBlock *h_poses[kPoseRing] = {};   // pinned staging
+    std::vector<PoseBlock> h_poses;       // this step's poses when they travel as kernel arguments
+    PoseBlock *h_ring[kPoseRing] = {};    // pinned staging otherwise (more than kPosePack envs)
     hipEvent_t pose_done[kPoseRing] = {};
     int ring = 0;
     FrameHeader *d_hdr = nullptr;
@@ -137,7 +138,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     hipFree(eng->d_disk); hipFree(eng->d_palette);
     for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
     for (int i = 0; i < kPoseRing; ++i) {
-        if (eng->h_poses[i]) hipHostFree(eng->h_poses[i]);
+        if (eng->h_ring[i]) hipHostFree(eng->h_ring[i]);
         if (eng->pose_done[i]) hipEventDestroy(eng->pose_done[i]);
     }
     delete eng;
@@ -218,8 +219,9 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     hipMemset(eng->d_pool_count, 0, 6 * sizeof(int32_t));
     hipMemset(eng->d_lut, 0, SSMAP_MAX_CLASSES * sizeof(int32_t));
 #undef TRY_ALLOC
-    for (int i = 0; i < kPoseRing; ++i) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&eng->h_poses[i]), sizeof(PoseBlock) * v.E) != hipSuccess ||
+    eng->h_poses.assign(c.n_envs, PoseBlock{});
+    for (int i = 0; i < kPoseRing && c.n_envs > kPosePack; ++i) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&eng->h_ring[i]), sizeof(PoseBlock) * v.E) != hipSuccess ||
             hipEventCreateWithFlags(&eng->pose_done[i], hipEventDisableTiming) != hipSuccess) {
             ssmap_destroy(eng);
             return fail(SSMAP_ERR_HIP, "pinned pose staging allocation failed");
@@ -355,10 +357,14 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     if (r != SSMAP_RULE_DIRECT && !f->semantic_gt) return fail(SSMAP_ERR_INVALID_ARG, "semantic_gt is required in probabilistic mode");
 
     // ---- pose preparation on the host (a few hundred flops per env)
+    const bool packed = c.n_envs <= kPosePack;
     const int slot = eng->ring;
-    eng->ring = (eng->ring + 1) % kPoseRing;
-    HIP_TRY(hipEventSynchronize(eng->pose_done[slot]));
-    PoseBlock *pb = eng->h_poses[slot];
+    PoseBlock *pb = eng->h_poses.data();
+    if (!packed) {
+        eng->ring = (eng->ring + 1) % kPoseRing;
+        HIP_TRY(hipEventSynchronize(eng->pose_done[slot]));
+        pb = eng->h_ring[slot];
+    }
     for (int e = 0; e < c.n_envs; ++e) {
         const double *ag = f->agent_pose + 7 * e, *cam = f->camera_pose + 7 * e;
         const ssmap_env_maps &mp = eng->envs[e].maps;
@@ -372,15 +378,18 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         b.goal_id = f->goal_sem_id[e];
         b.pad = 0;
     }
-    HIP_TRY(hipMemcpyAsync(eng->d_poses, pb, sizeof(PoseBlock) * c.n_envs, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(eng->pose_done[slot], stream));
+
+    if (!packed) {
+        HIP_TRY(hipMemcpyAsync(eng->d_poses, pb, sizeof(PoseBlock) * c.n_envs, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(eng->pose_done[slot], stream));
+    }
 
     hipEvent_t *marks = nullptr;
     if (eng->prof_capacity && eng->prof_steps < eng->prof_capacity)
         marks = eng->prof_events.data() + (size_t)kProfMarks * eng->prof_steps++;
 #define MARK(i) do { if (marks) HIP_TRY(hipEventRecord(marks[i], stream)); } while (0)
     MARK(0);
-    launch_geometry(v, *f, stream);
+    launch_geometry(v, *f, packed ? pb : nullptr, stream);
     MARK(1);
     launch_winners(v, stream);
     launch_resolve_wrapped(v, stream);

@@ -1,5 +1,4 @@
 // Stages 2 and 3 of the fusion path for gfx950:
-//   k_begin_step  resets the per-env frame headers
 //   k_geometry    depth -> world point -> map cell + height, one pass over the depth image
 //                 (mapper.py:279-283 sentinels, :18-32 pointcloud, :305-311 rotate/translate,
 //                  :851-863 world2map, :319-329 masks)
@@ -9,6 +8,7 @@
 // This file is compiled with -ffp-contract=off: the float64 geometry must round exactly
 // like the CPU statement of the same formulas (explicit fma only where written).
 #include "ssmap_internal.h"
+#include <cstring>
 
 namespace ssmap {
 
@@ -54,12 +54,18 @@ __device__ inline double floor_div_known(double d, double p, double rp) {
 }
 
 // One thread = 4 horizontally adjacent pixels (W % 4 == 0 is checked on the host).
+// PACKED: the poses arrive as a kernel argument (batches of at most kPosePack envs: no
+// host-to-device copy in front of the step) and block 0 of every env stores its pose for the
+// later kernels; otherwise the poses are already in v.poses.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all,
-                                                  int write_target) {
+                                                  int write_target, PosePack pack) {
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const PoseBlock &pb = v.poses[e];
+    const PoseBlock &pb = PACKED ? pack.p[blockIdx.y] : v.poses[e];
+    if (PACKED && blockIdx.x == 0 && threadIdx.x < sizeof(PoseBlock) / 8)
+        reinterpret_cast<double *>(v.poses + e)[threadIdx.x] = reinterpret_cast<const double *>(&pb)[threadIdx.x];
     const ssmap_env_maps &mp = v.envs[e].maps;
     const int Hm = mp.map_h, Wm = mp.map_w;
 
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
 }
 
 // One block per env: folds the geometry blocks' partials into the frame header and resets the
-// per-step counters.
+// per-step counters.  (Folding inside every k_bin_count block instead was measured slower.)
 __global__ __launch_bounds__(256) void k_frame_header(View v, int nblk) {
     __shared__ int s_red[4][6];
     const int e = blockIdx.x;
@@ -629,10 +635,16 @@ void launch_resolve_wrapped(const View &v, hipStream_t s) {
 }
 
 
-void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s) {
+void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
-    hipLaunchKernelGGL(k_geometry, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
+    PosePack pack;
+    if (host_poses) {   // at most kPosePack envs
+        memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);
+        hipLaunchKernelGGL(k_geometry<true>, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0, pack);
+    } else {
+        hipLaunchKernelGGL(k_geometry<false>, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0, pack);
+    }
     hipLaunchKernelGGL(k_frame_header, dim3(v.E), dim3(256), 0, s, v, (int)grid.x);
 }
 

@@ -37,6 +37,14 @@ struct PoseBlock {
     int32_t pad;
 };
 
+// Engines of at most kPosePack envs hand the poses to the geometry kernel as a kernel argument
+// (no host-to-device copy in front of every step); the kernel stores them for the later kernels
+// of the step.  Larger engines copy them through a pinned staging ring.
+constexpr int kPosePack = 16;
+struct PosePack {
+    PoseBlock p[kPosePack];
+};
+
 // Per-env scratch header, rewritten every step.
 struct FrameHeader {
     int32_t rmin, rmax, cmin, cmax;       // bbox of all live pixels' cells (unwrapped)
@@ -65,7 +73,7 @@ struct View {
     double inv_fx, inv_fy, inv_p2m;   // correctly rounded reciprocals (host division)
     // scratch (device)
     const EnvState *envs;
-    const PoseBlock *poses;
+    PoseBlock *poses;          // [E] written by the geometry kernel, read by the later kernels
     FrameHeader *hdr;
     uint32_t *cellid;          // [E][N]
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
@@ -108,7 +116,7 @@ __host__ __device__ inline double unorder_f64(unsigned long long k) {
 }
 
 // launchers (defined in the .hip files)
-void launch_geometry(const View &v, const ssmap_frames &f, hipStream_t s);
+void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s);
 void launch_winners(const View &v, hipStream_t s);
 void launch_resolve_wrapped(const View &v, hipStream_t s);
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);

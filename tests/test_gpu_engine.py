@@ -205,19 +205,23 @@ def test_full_size_label_rules_from_logits(rule, attrs, filt):
     eng.close()
 
 
-def test_batched_engine_equals_independent_engines():
-    """E = 3 envs with different map sizes and poses in one call == three E = 1 engines."""
+@pytest.mark.parametrize("n_envs", [3, 18])
+def test_batched_engine_equals_independent_engines(n_envs):
+    """E envs with different map sizes and poses in one call == E engines of one env each.
+    (Up to 16 envs the poses travel as kernel arguments, above through a staging copy.)"""
     import semantic_search_amd as ssa
     h, w, c = 96, 128, 8
     lut = scenes.small_lut(c)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
-    bounds = [np.array([0, 0, 0, 4.5, 2.5, 4.5]), np.array([-1.0, 0, -2.0, 5.0, 2.5, 3.1]),
-              np.array([0.3, 0, 0.2, 3.0, 2.5, 6.0])]
-    big = ssa.MapEngine(3, (h, w), max_map_hw=(200, 200), **kw)
+    base = [np.array([0, 0, 0, 4.5, 2.5, 4.5]), np.array([-1.0, 0, -2.0, 5.0, 2.5, 3.1]),
+            np.array([0.3, 0, 0.2, 3.0, 2.5, 6.0])]
+    bounds = [base[e % 3] for e in range(n_envs)]
+    goals = [3 + (e % 2) for e in range(n_envs)]
+    big = ssa.MapEngine(n_envs, (h, w), max_map_hw=(200, 200), **kw)
     big.set_schema(lut)
     singles = []
-    for e in range(3):
+    for e in range(n_envs):
         big.reset_env(e, bounds[e])
         s = ssa.MapEngine(1, (h, w), max_map_hw=(200, 200), **kw)
         s.set_schema(lut)
@@ -226,23 +230,23 @@ def test_batched_engine_equals_independent_engines():
     rng = np.random.default_rng(3)
     for i in range(3):
         frames, ag, cam = [], [], []
-        for e in range(3):
-            a, cm = scenes.make_pose(1.5 + 0.2 * e, 0.0, 1.2 + 0.3 * i, rng.uniform(0, 6.28))
+        for e in range(n_envs):
+            a, cm = scenes.make_pose(1.5 + 0.2 * (e % 5), 0.0, 1.2 + 0.3 * i, rng.uniform(0, 6.28))
             frames.append(scenes.room_frame(rng, h, w, c, 1.0, cm, lut=lut))
             ag.append(a)
             cam.append(cm)
         depth = np.stack([f["depth"] for f in frames])
         probs = np.stack([f["semantic_prob"] for f in frames])
         gt = np.stack([f["semantic_gt"] for f in frames])
-        big.step(_to_dev(depth, np.float32), np.stack(ag), np.stack(cam), [3, 4, 3],
+        big.step(_to_dev(depth, np.float32), np.stack(ag), np.stack(cam), goals,
                  probs=_to_dev(probs, np.float32), semantic_gt=_to_dev(gt, np.int32))
         fb, sb, nb = big.results()
-        for e in range(3):
-            singles[e].step(_to_dev(depth[e:e + 1], np.float32), ag[e][None], cam[e][None], [[3, 4, 3][e]],
+        for e in range(n_envs):
+            singles[e].step(_to_dev(depth[e:e + 1], np.float32), ag[e][None], cam[e][None], [goals[e]],
                             probs=_to_dev(probs[e:e + 1], np.float32), semantic_gt=_to_dev(gt[e:e + 1], np.int32))
             f1, s1_, n1 = singles[e].results()
             assert (fb[e], sb[e], nb[e]) == (f1[0], s1_[0], n1[0])
-    for e in range(3):
+    for e in range(n_envs):
         for nm, t in big.maps[e].items():
             assert torch.equal(t, singles[e].maps[0][nm]), (e, nm)
     big.close()

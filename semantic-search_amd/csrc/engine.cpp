@@ -131,7 +131,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec_h); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -191,7 +191,10 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&v.cellid, EN));
     TRY_ALLOC(dev_alloc(&v.horder, EN));
     TRY_ALLOC(dev_alloc(&v.geo_part, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * 8));
-    TRY_ALLOC(dev_alloc(&v.rec, EN));
+    TRY_ALLOC(dev_alloc(&v.rec_h, EN * 2));   // height images, then the record words, then the slots
+    v.rec_w = reinterpret_cast<uint32_t *>(v.rec_h + EN);
+    v.rec_s = v.rec_w + EN;
+    v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
     TRY_ALLOC(dev_alloc(&v.bin_cnt, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * kMaxParts));
     TRY_ALLOC(dev_alloc(&v.part_start, (size_t)v.E * (kMaxParts + 1)));
     if (prob_rule) {

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
     }
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
     __shared__ unsigned int cnt[kMaxParts];
     __shared__ unsigned int base[kMaxParts];
@@ -337,15 +338,19 @@ __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
     const ulonglong2 h01 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0);
     const ulonglong2 h23 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0 + 2);
     const unsigned long long hk[4] = {h01.x, h01.y, h23.x, h23.y};
-    uint4 *recs = v.rec + fbase;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (ids[k] == kDeadCell) continue;
         int part, slot;
         split_cell(bin_cell(f, ids[k]), f.nparts, part, slot);
         const unsigned pos = base[part] + atomicAdd(&cnt[part], 1u);
-        const unsigned word = ((unsigned)(i0 + k) << 1) | ((ids[k] & kUpdBit) ? 0u : 1u);
-        recs[pos] = make_uint4(word, (unsigned)slot, (unsigned)hk[k], (unsigned)(hk[k] >> 32));
+        v.rec_h[fbase + pos] = hk[k];
+        if (PACKED) {
+            v.rec_w[fbase + pos] = ((unsigned)slot << kPackPixBits) | (unsigned)(i0 + k);
+        } else {
+            v.rec_w[fbase + pos] = (unsigned)(i0 + k);
+            v.rec_s[fbase + pos] = (unsigned)slot;
+        }
     }
 }
 
@@ -364,7 +369,44 @@ struct WinnerShared {
     int s_box[kWinnerThreads / 64][4];
 };
 
-template <bool RUNS>
+// One binned record in registers.  The not-updatable flag is not stored: a pixel in a table has
+// valid depth and lies inside the upper bounds, so it is updatable exactly when its height is
+// below the cut-off, which the table's winning height tells.
+template <bool PACKED>
+struct Rec;
+template <>
+struct Rec<true> {
+    unsigned long long h;
+    uint32_t w;
+    __device__ uint32_t slot() const { return w >> kPackPixBits; }
+    __device__ uint32_t word() const { return (w & ((1u << kPackPixBits) - 1u)) << 1; }   // pixel << 1
+};
+template <>
+struct Rec<false> {
+    unsigned long long h;
+    uint32_t w, s;
+    __device__ uint32_t slot() const { return s; }
+    __device__ uint32_t word() const { return w << 1; }
+};
+template <bool PACKED>
+__device__ inline Rec<PACKED> load_rec(const View &v, int64_t fbase, unsigned t);
+template <>
+__device__ inline Rec<true> load_rec<true>(const View &v, int64_t fbase, unsigned t) {
+    Rec<true> r;
+    r.h = v.rec_h[fbase + t];
+    r.w = v.rec_w[fbase + t];
+    return r;
+}
+template <>
+__device__ inline Rec<false> load_rec<false>(const View &v, int64_t fbase, unsigned t) {
+    Rec<false> r;
+    r.h = v.rec_h[fbase + t];
+    r.w = v.rec_w[fbase + t];
+    r.s = v.rec_s[fbase + t];
+    return r;
+}
+
+template <bool RUNS, bool PACKED>
 __device__ __forceinline__ void winners_body(const View &v, int write_target, int write_list, WinnerShared &sh) {
     unsigned long long (&table_h)[kSlots] = sh.table_h;
     unsigned int (&table_i)[kSlots] = sh.table_i;
@@ -412,11 +454,10 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     const unsigned long long *hk = v.horder + fbase;
     const int n4 = v.N >> 2;
     // binned records of this frame, contiguous per table
-    const uint4 *recs = v.rec + fbase;
     const unsigned int *part_start = v.part_start + e * (kMaxParts + 1);
     constexpr int kRunBatch = 4;
-    constexpr int kKeep = RUNS ? 14 : 1;   // records per thread kept in registers between the phases
-    uint4 keep[kKeep];
+    constexpr int kKeep = RUNS ? (PACKED ? 19 : 14) : 1;   // records per thread kept in registers between the phases
+    Rec<PACKED> keep[kKeep];
     int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
     if (threadIdx.x == 0) s_neg = 0;
 
@@ -434,23 +475,23 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 #pragma unroll
             for (int u = 0; u < kKeep; ++u) {
                 const unsigned t = rec_beg + threadIdx.x + u * kWinnerThreads;
-                if (t < rec_end) keep[u] = recs[t];
+                if (t < rec_end) keep[u] = load_rec<PACKED>(v, fbase, t);
             }
 #pragma unroll
             for (int u = 0; u < kKeep; ++u)
                 if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end)
-                    atomicMax(&table_h[keep[u].y], ((unsigned long long)keep[u].w << 32) | keep[u].z);
+                    atomicMax(&table_h[keep[u].slot()], keep[u].h);
             for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
-                uint4 rec[kRunBatch];
+                Rec<PACKED> rec[kRunBatch];
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u) {
                     const unsigned t = t0 + u * kWinnerThreads;
-                    if (t < rec_end) rec[u] = recs[t];
+                    if (t < rec_end) rec[u] = load_rec<PACKED>(v, fbase, t);
                 }
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u)
                     if (t0 + u * kWinnerThreads < rec_end)
-                        atomicMax(&table_h[rec[u].y], ((unsigned long long)rec[u].w << 32) | rec[u].z);
+                        atomicMax(&table_h[rec[u].slot()], rec[u].h);
             }
         } else {
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
@@ -478,20 +519,20 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 #pragma unroll
             for (int u = 0; u < kKeep; ++u)
                 if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end &&
-                    table_h[keep[u].y] == (((unsigned long long)keep[u].w << 32) | keep[u].z))
-                    atomicMin(&table_i[keep[u].y], keep[u].x);
+                    table_h[keep[u].slot()] == keep[u].h)
+                    atomicMin(&table_i[keep[u].slot()], keep[u].word());
             for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
-                uint4 rec[kRunBatch];
+                Rec<PACKED> rec[kRunBatch];
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u) {
                     const unsigned t = t0 + u * kWinnerThreads;
-                    if (t < rec_end) rec[u] = recs[t];
+                    if (t < rec_end) rec[u] = load_rec<PACKED>(v, fbase, t);
                 }
 #pragma unroll
                 for (int u = 0; u < kRunBatch; ++u)
                     if (t0 + u * kWinnerThreads < rec_end &&
-                        table_h[rec[u].y] == (((unsigned long long)rec[u].w << 32) | rec[u].z))
-                        atomicMin(&table_i[rec[u].y], rec[u].x);
+                        table_h[rec[u].slot()] == rec[u].h)
+                        atomicMin(&table_i[rec[u].slot()], rec[u].word());
             }
         } else {
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
@@ -507,7 +548,7 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
                 if ((L >> kSlotShift) == p) {
                     const int s = L & (kSlots - 1);
                     if (hk[4 * q + k] == table_h[s])
-                        atomicMin(&table_i[s], ((unsigned)(4 * q + k) << 1) | ((id & kUpdBit) ? 0u : 1u));
+                        atomicMin(&table_i[s], (unsigned)(4 * q + k) << 1);
                 }
             }
         }
@@ -521,7 +562,9 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const unsigned w = table_i[it * kWinnerThreads + threadIdx.x];
-            balls[it] = __ballot(w != kNoPixel && !(w & 1u));
+            // updatable: not the invalid-depth entry, and below the height cut-off
+            balls[it] = __ballot(w != kNoPixel && !(w & 1u) &&
+                                 unorder_f64(table_h[it * kWinnerThreads + threadIdx.x]) < pb.h_cut);
             if (lane == 0) s_cnt[it * kWaves + wave] = (unsigned)__popcll(balls[it]);
         }
         __syncthreads();
@@ -592,8 +635,9 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_ta
     const FrameHeader *hdr = v.hdr + blockIdx.y;
     const long long ncell = (long long)(hdr->cmax - hdr->cmin + 1) * (long long)(hdr->rmax - hdr->rmin + 1);
     if (hdr->rmin > hdr->rmax) return;
-    if (((ncell + kSlots - 1) >> kSlotShift) <= kMaxParts) winners_body<true>(v, write_target, write_list, sh);
-    else winners_body<false>(v, write_target, write_list, sh);
+    if (((ncell + kSlots - 1) >> kSlotShift) > kMaxParts) winners_body<false, false>(v, write_target, write_list, sh);
+    else if (v.rec_packed) winners_body<true, true>(v, write_target, write_list, sh);
+    else winners_body<true, false>(v, write_target, write_list, sh);
 }
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
@@ -655,7 +699,8 @@ void launch_winners(const View &v, hipStream_t s) {
     dim3 grid_bin(nbin, v.E);
     hipLaunchKernelGGL(k_bin_count, grid_bin, dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_bin_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
-    hipLaunchKernelGGL(k_bin_scatter, grid_bin, dim3(256), 0, s, v);
+    if (v.rec_packed) hipLaunchKernelGGL(k_bin_scatter<true>, grid_bin, dim3(256), 0, s, v);
+    else hipLaunchKernelGGL(k_bin_scatter<false>, grid_bin, dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
 }
 

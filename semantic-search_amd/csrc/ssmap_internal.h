@@ -20,6 +20,7 @@ constexpr uint32_t kLostBit = 1u << 29;       // ... another update pixel owns t
 constexpr uint32_t kPixMask = (1u << 29) - 1;
 constexpr int kSlots = 8192;                  // cells per LDS winner table
 constexpr int kSlotShift = 13;
+constexpr int kPackPixBits = 32 - kSlotShift;   // slot and pixel share one record word when N <= 2^19
 constexpr int kGeomPixPerBlock = 1024;        // geometry kernel: 256 threads x 4 pixels
 constexpr int kWinnerThreads = 1024;
 constexpr int kMaxParts = 64;                // binned path: tables per frame (cell box <= 512 Ki cells)
@@ -78,7 +79,12 @@ struct View {
     uint32_t *cellid;          // [E][N]
     unsigned long long *horder;// [E][N] order-preserving image of the f64 height
     int32_t *geo_part;         // [E][N/1024][8] per-geometry-block bbox / invalid pixel / error partials
-    uint4 *rec;                // [E][N] binned pixel records (k_bin)
+    // binned pixel records, one array per field, contiguous per winner table (k_bin_*):
+    unsigned long long *rec_h; // [E][N] height image
+    uint32_t *rec_w;           // [E][N] slot << kPackPixBits | pixel when the frame has at most
+                               //        2^kPackPixBits pixels (rec_packed), else the pixel
+    uint32_t *rec_s;           // [E][N] slot (only when !rec_packed)
+    int32_t rec_packed;
     unsigned int *bin_cnt;     // [E][N/1024][kMaxParts] per-block table counts, then record bases
     unsigned int *part_start;  // [E][kMaxParts+1] first record of each table
     int32_t *target;           // [E][N] slot of this pixel in the frame's update list, or -1

@@ -145,6 +145,17 @@ def test_full_size_probability_rules(rule, from_logits):
     eng.close()
 
 
+def test_frame_above_packed_record_limit():
+    """768x704 = 540 672 pixels: above 2^19, so the binned records carry slot and pixel in
+    separate words.  Update set, height and ground-truth maps exact, fused map within tolerance."""
+    eng, maps, ref, log = _run_pair("height_map_avg_prob", 8, 1.0, 2, (704, 768), False,
+                                    attrs=dict(entropy_threshold=0.43759))
+    _close(maps["avg_prob_seg_map"].cpu().numpy(), ref.avg_prob_seg_map, "avg_prob_seg_map")
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+    eng.close()
+
+
 def test_segformer_style_150_classes_w2():
     eng, maps, ref, log = _run_pair("height_map_w2_avg_prob", 150, 2.5, 2, (120, 160), True,
                                     attrs=dict(entropy_threshold=0.482), bounds=BOUNDS_480)

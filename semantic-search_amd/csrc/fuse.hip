@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
 template <int MODE, int V, int K>
 __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__restrict__ gt) {
     typedef float VecF __attribute__((ext_vector_type(V)));
-    constexpr int NB = 2;             // row-batches in flight per wave
+    constexpr int NB = V * K <= 4 ? 4 : 2;   // row-batches in flight per wave (of the 4 a pass needs)
     constexpr unsigned kRun = 64;     // list slots per block pass
     __shared__ int s_bi[kRun];
     __shared__ float s_wn[kRun], s_ent[kRun];
@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
             bool live[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const unsigned i = r0 + 16 * wave + 4 * (b0 + b) + row;
-                const int2 pc = i < n ? list[i] : make_int2((int)kLostBit, 0);
+                // the list entry of this row's slot sits in lane j of the side load above
+                const int j = 16 * wave + 4 * (b0 + b) + row;
+                const unsigned i = r0 + j;
+                const int2 pc = make_int2(__shfl(ps.x, j), __shfl(ps.y, j));
                 live[b] = !((uint32_t)pc.x & kLostBit);
                 cell[b] = pc.y;
                 w_old[b] = 0.0f;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
 #pragma unroll
                             for (int j = 0; j < V; ++j) {
                                 hs += entr(mv[b][k][j] / sm);
-                                if (arg_better(mv[b][k][j], c + j, best, bi)) { best = mv[b][k][j]; bi = c + j; }
+                                { const bool take = arg_better(mv[b][k][j], c + j, best, bi); best = take ? mv[b][k][j] : best; bi = take ? c + j : bi; }
                             }
                         }
                     }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
 #pragma unroll
                             for (int j = 0; j < V; ++j) {
                                 mv[b][k][j] = mv[b][k][j] + __logf(p[b][k][j] / p0);
-                                if (arg_better(mv[b][k][j], c + j, best, bi)) { best = mv[b][k][j]; bi = c + j; }
+                                { const bool take = arg_better(mv[b][k][j], c + j, best, bi); best = take ? mv[b][k][j] : best; bi = take ? c + j : bi; }
                             }
                             *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];
                         }
@@ -423,7 +425,9 @@ static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs 
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
-    dim3 grid(256, v.E), block(256);
+    // 64 list slots per block pass: 384 blocks take a typical frame's 15-25 thousand update cells
+    // in one pass each (a grid just short of that makes the whole kernel wait for a second pass)
+    dim3 grid(384, v.E), block(256);
     const bool lo = v.rule == SSMAP_RULE_LOG_ODDS;
     // widest vector that divides C (every cell row and staged row then starts on a vector boundary;
     // engine scratch is 256-byte aligned, bound maps are checked when they are bound)

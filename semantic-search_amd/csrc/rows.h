@@ -6,12 +6,13 @@
 
 namespace ssmap {
 
-// numpy argmax order: NaN beats everything, ties go to the lower index
+// numpy argmax order: NaN beats everything, ties go to the lower index.  Written without
+// short-circuit operators so that it compiles to compares and selects, not branches.
 __device__ inline bool arg_better(float a, int ia, float b, int ib) {
     const bool an = a != a, bn = b != b;
-    if (an != bn) return an;
-    if (an) return ia < ib;
-    return a > b || (a == b && ia < ib);
+    const bool lower = ia < ib;
+    const bool num = (a > b) | ((a == b) & lower);
+    return an ? (!bn | lower) : (!bn & num);
 }
 // After the four rotate steps every lane of a row holds the reduction over the row.
 template <int N>
@@ -30,7 +31,9 @@ template <int N>
 __device__ inline void row_argmax_step(float &val, int &idx) {
     const float ov = row_ror<N>(val);
     const int oi = row_ror<N>(idx);
-    if (arg_better(ov, oi, val, idx)) { val = ov; idx = oi; }
+    const bool take = arg_better(ov, oi, val, idx);
+    val = take ? ov : val;
+    idx = take ? oi : idx;
 }
 __device__ inline void row_argmax(float &val, int &idx) {
     row_argmax_step<8>(val, idx); row_argmax_step<4>(val, idx);

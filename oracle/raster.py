@@ -76,3 +76,18 @@ def dilate_same(mask: np.ndarray, size: int) -> np.ndarray:
         for j in range(size):
             out |= pad[i : i + h, j : j + w]
     return out
+
+
+def dilate_max(img: np.ndarray, kh: int, kw: int) -> np.ndarray:
+    """Grey dilation by a kh x kw box anchored at (kh//2, kw//2), OpenCV's `dilate` with the
+    default border: cells outside the image do not take part in the maximum."""
+    h, w = img.shape
+    ay, ax = kh // 2, kw // 2
+    low = np.iinfo(img.dtype).min if np.issubdtype(img.dtype, np.integer) else -np.inf
+    pad = np.full((h + kh, w + kw), low, dtype=img.dtype)
+    pad[ay : ay + h, ax : ax + w] = img
+    out = np.full((h, w), low, dtype=img.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            out = np.maximum(out, pad[i : i + h, j : j + w])
+    return out

@@ -26,6 +26,60 @@ _RULE_ATTRS = ("entropy_threshold", "goal_decay", "goal_mark", "hv_ratio", "hv_m
                "hv_limit_obj_view_dist")
 
 
+def _box_cells(center, sizes, lower, pixel2meter, shape):
+    """Half-open cell rectangle of an axis-aligned box: both corners through world2map, every
+    index clipped to the map (mapper.py:1063-1072)."""
+    lo = np.asarray(center, dtype=np.float64) - np.asarray(sizes, dtype=np.float64) - lower
+    hi = np.asarray(center, dtype=np.float64) + np.asarray(sizes, dtype=np.float64) - lower
+    r1, c1 = int(np.floor(lo[2] / pixel2meter)), int(np.floor(lo[0] / pixel2meter))
+    r2, c2 = int(np.floor(hi[2] / pixel2meter)), int(np.floor(hi[0] / pixel2meter))
+    clip = lambda v, n: min(max(v, 0), n - 1)
+    return clip(r1, shape[0]), clip(r2, shape[0]), clip(c1, shape[1]), clip(c2, shape[1])
+
+
+def _dilate_box(mask, size):
+    """Binary dilation by a size x size box anchored at its centre, nothing outside the map."""
+    h, w = mask.shape
+    a = size // 2
+    pad = np.zeros((h + size, w + size), dtype=bool)
+    pad[a:a + h, a:a + w] = mask
+    out = np.zeros((h, w), dtype=bool)
+    for i in range(size):
+        for j in range(size):
+            out |= pad[i:i + h, j:j + w]
+    return out
+
+
+def fp_fn_detections(semantic_map, gt_map, goal_sem_id, centers, sizes, lower, pixel2meter,
+                     hits=None, views=None):
+    """(fp, fn, is_fn_bbox) of mapper.py:1053-1112 on host arrays.  A box counts only if the
+    ground-truth map holds the goal inside it; it is a false negative if the map shows no goal
+    there (hit/view rules: no cell with hits > 0 and finite views).  False positives are the
+    8-connected blobs of predicted goal cells outside all counted boxes, after a box dilation of
+    int(0.1 / pixel2meter) cells."""
+    import scipy.ndimage
+    lower = np.asarray(lower, dtype=np.float64)
+    shape = semantic_map.shape
+    pred = semantic_map == goal_sem_id
+    counted = np.zeros(shape, dtype=bool)
+    fn, is_fn = 0, []
+    for center, size in zip(centers, sizes):
+        r1, r2, c1, c2 = _box_cells(center, size, lower, pixel2meter, shape)
+        if not (gt_map[r1:r2, c1:c2] == goal_sem_id).any():
+            is_fn.append(False)
+            continue
+        counted[r1:r2, c1:c2] = True
+        if hits is not None:
+            seen = bool(((hits[r1:r2, c1:c2] > 0) & (views[r1:r2, c1:c2] != np.inf)).any())
+        else:
+            seen = bool(pred[r1:r2, c1:c2].any())
+        is_fn.append(not seen)
+        fn += 0 if seen else 1
+    fp_mask = _dilate_box(pred & ~counted, int(0.1 / pixel2meter))
+    _, fp = scipy.ndimage.label(fp_mask, scipy.ndimage.generate_binary_structure(2, 2))
+    return int(fp), fn, is_fn
+
+
 class SemanticMapper:
     def __init__(
         self,
@@ -241,7 +295,16 @@ class SemanticMapper:
         return uv + world_lower_bound_m[[0, 2]]
 
     def compute_fp_fn_detections(self, task_goal_ids, bboxes):
-        raise NotImplementedError("compute_fp_fn_detections is not built yet")
+        """Per-episode detection metric (mapper.py:1053-1112): false-negative goal boxes and
+        the number of false-positive goal blobs on the map.  `bboxes` have `.center` and
+        `.sizes` (world metres).  Runs on the host over the downloaded maps, once per episode."""
+        goal_sem_id = self.goal2sem_id[task_goal_ids][0]
+        hv = self.probablistic_mapping and ("hv" in self.prob_aggregate)
+        semantic_map = self.semantic_map
+        gt_map = self.gt_map if self.probablistic_mapping else semantic_map   # alias, mapper.py:257
+        return fp_fn_detections(semantic_map, gt_map, goal_sem_id, [b.center for b in bboxes],
+                                [b.sizes for b in bboxes], self.map_bounds[:3], self.pixel2meter,
+                                hits=self.hits if hv else None, views=self.views if hv else None)
 
     # ------------------------------------------------------------------ public map arrays
     def _host(self, name):

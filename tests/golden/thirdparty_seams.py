@@ -177,10 +177,30 @@ def erode(src, kernel, iterations=1, **k):
     return out
 
 
+def dilate(src, kernel, iterations=1, **k):
+    """Maximum over the kernel footprint anchored at its centre; cells outside the image do not
+    take part (OpenCV's default border value for dilation is the type's minimum)."""
+    assert iterations == 1
+    kh, kw = kernel.shape
+    ay, ax = kh // 2, kw // 2
+    h, w = src.shape
+    low = np.iinfo(src.dtype).min if np.issubdtype(src.dtype, np.integer) else -np.inf
+    pad = np.full((h + kh, w + kw), low, dtype=src.dtype)
+    pad[ay : ay + h, ax : ax + w] = src
+    out = np.full((h, w), low, dtype=src.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            if kernel[i, j]:
+                out = np.maximum(out, pad[i : i + h, j : j + w])
+    return out
+
+
 def _make_cv2():
     m = types.ModuleType("cv2")
     m.circle = circle
     m.erode = erode
+    m.dilate = dilate
+    m.getStructuringElement = lambda shape, ksize: np.ones((ksize[1], ksize[0]), dtype=np.uint8)
     m.line = lambda img, p0, p1, color, thickness=1, *a, **k: img
     m.getRotationMatrix2D = lambda c, ang, s: np.zeros((2, 3))
     m.warpAffine = lambda src, M, dsize, **k: np.zeros_like(src)

@@ -1,0 +1,71 @@
+"""Per-episode detection metric (mapper.py:1053-1112): the oracle and the product's host
+function against outputs of the reference method itself (tests/golden/metrics/fpfn.npz, written by
+tests/golden/make_fpfn_golden.py; the 3x3 dilation is the one seam the reference run took from
+a restatement)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import metrics_oracle
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics", "fpfn.npz"))
+NAMES = [str(n) for n in GOLD["names"]]
+GOAL2SEM = np.array([3, 4, 5, 6, 7, 8])      # num_semantic_classes = 9 (mapper.py:139-140)
+
+
+def _case(name):
+    hv = "hv" in str(GOLD[f"{name}_rule"]) and bool(GOLD[f"{name}_prob"])
+    return dict(
+        semantic_map=GOLD[f"{name}_semantic_map"], gt_map=GOLD[f"{name}_gt_map"],
+        goal=int(GOAL2SEM[int(GOLD[f"{name}_goal_index"])]),
+        centers=GOLD[f"{name}_centers"], sizes=GOLD[f"{name}_sizes"],
+        hits=GOLD[f"{name}_hits"] if hv else None, views=GOLD[f"{name}_views"] if hv else None,
+        want=(int(GOLD[f"{name}_fp"]), int(GOLD[f"{name}_fn"]), [bool(b) for b in GOLD[f"{name}_is_fn_bbox"]]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_outputs(name):
+    c = _case(name)
+    got = metrics_oracle.fp_fn_detections(c["semantic_map"], c["gt_map"], c["goal"], c["centers"], c["sizes"],
+                                          GOLD["bounds"][:3], 0.03, hits=c["hits"], views=c["views"])
+    assert (got[0], got[1], list(got[2])) == c["want"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_product_host_function_matches_reference_outputs(name):
+    from semantic_search_amd.mapper import fp_fn_detections
+    c = _case(name)
+    got = fp_fn_detections(c["semantic_map"], c["gt_map"], c["goal"], c["centers"], c["sizes"],
+                           GOLD["bounds"][:3], 0.03, hits=c["hits"], views=c["views"])
+    assert (got[0], got[1], list(got[2])) == c["want"]
+
+
+def test_fixture_exercises_both_outcomes():
+    fns = sum(int(GOLD[f"{n}_fn"]) for n in NAMES)
+    fps = sum(int(GOLD[f"{n}_fp"]) for n in NAMES)
+    assert fns >= 5 and fps >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_mapper_method_on_device_maps(name):
+    """`SemanticMapper.compute_fp_fn_detections` over maps that live on the GPU."""
+    import torch
+    import semantic_search_amd as ssa
+    c = _case(name)
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                           probablistic_mapping=bool(GOLD[f"{name}_prob"]), prob_aggregate=str(GOLD[f"{name}_rule"]))
+    m.reset(GOLD["bounds"].copy())
+    m._ensure_engine(48, 64)
+    maps = m._engine.maps[0]
+    maps["semantic_map"].copy_(torch.from_numpy(c["semantic_map"].view(np.int32)))
+    if "gt_map" in maps:
+        maps["gt_map"].copy_(torch.from_numpy(c["gt_map"].view(np.int32)))
+    if c["hits"] is not None:
+        maps["hits"].copy_(torch.from_numpy(c["hits"]))
+        maps["views"].copy_(torch.from_numpy(c["views"]))
+    boxes = [types.SimpleNamespace(center=ce, sizes=sz) for ce, sz in zip(c["centers"], c["sizes"])]
+    fp, fn, is_fn = m.compute_fp_fn_detections(np.array([int(GOLD[f"{name}_goal_index"])]), boxes)
+    assert (fp, fn, list(is_fn)) == c["want"]

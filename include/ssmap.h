@@ -59,6 +59,7 @@ typedef enum ssmap_rule {
 #define SSMAP_MAX_CLASSES 256
 #define SSMAP_MAX_MAP_DIM 8192
 #define SSMAP_MAX_POOL 8
+#define SSMAP_MAX_AUX 32
 
 /* Fixed for the life of an engine: SemanticMapper.__init__ arguments (mapper.py:49-72)
  * plus the frame geometry. */
@@ -168,6 +169,34 @@ int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev);
  * (stage_ms[5]) and the number of recorded steps, and rearms. */
 int ssmap_profile_begin(ssmap_engine *eng, int32_t max_steps);
 int ssmap_profile_read(ssmap_engine *eng, double *stage_ms, int32_t *n_steps, void *stream);
+
+/* Egocentric observation maps, `SemanticMapper.ego_map` (mapper.py:876-998): crop around the
+ * agent (large crop + offset_for_cut), goal cells recoloured, nearest-neighbour rotation by the
+ * heading, agent disk and auxiliary-angle squares drawn on top, centre crops of the small and
+ * the large side, INTER_AREA resize to out_w x out_h (uncertainty: border -0.5, nearest resize).
+ * The constants are the ones the reference derives in its constructor (mapper.py:77-109). */
+typedef struct ssmap_egomap_config {
+    int32_t small_crop_px, large_crop_px;   /* int(egomap_*_side_m / pixel2meter), mapper.py:91-95 */
+    int32_t offset_for_cut;                 /* 150, mapper.py:96 */
+    int32_t out_w, out_h;                   /* egomap_size, mapper.py:98 */
+    int32_t agent_radius_px;                /* mapper.py:97 */
+    int32_t aux_bin_px;                     /* mapper.py:100 */
+    int32_t n_aux;                          /* aux_num_bins, <= SSMAP_MAX_AUX */
+    int32_t aux_points[2 * SSMAP_MAX_AUX];  /* (row, col) offsets from the image centre, mapper.py:82-89 */
+    uint8_t active_goal_color[3];           /* mapper.py:103 */
+    uint8_t arrow_color[3];                 /* mapper.py:106-108 */
+    uint8_t pad[2];
+} ssmap_egomap_config;
+int ssmap_set_egomap(ssmap_engine *eng, const ssmap_egomap_config *cfg);
+
+/* One set of ego maps per env from the maps as they stand (call after ssmap_step).
+ * agent_pose: host [E][7] = x,y,z,qw,qx,qy,qz; goal_sem_id: host [E]; aux_color: host
+ * [E][n_aux][3] = (aux_pred_color * onehot[j]).astype(uint8) (mapper.py:1038) or NULL for no
+ * auxiliary squares.  Outputs are device arrays: ego_small / ego_large [E][out_h][out_w][3] u8,
+ * unc_small / unc_large [E][out_h][out_w] f32 (may be NULL; they need unc_map bound). */
+int ssmap_ego_maps(ssmap_engine *eng, const double *agent_pose, const int32_t *goal_sem_id,
+                   const uint8_t *aux_color, uint8_t *ego_small, uint8_t *ego_large,
+                   float *unc_small, float *unc_large, void *stream);
 
 const char *ssmap_last_error(void);
 const char *ssmap_version(void);

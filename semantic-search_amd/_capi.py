@@ -17,7 +17,8 @@ ENV_INDEX_ERROR = 1
 
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
            "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_stage1",
-           "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read", "ssmap_last_error", "ssmap_version")
+           "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
+           "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_last_error", "ssmap_version")
 
 
 class Config(C.Structure):
@@ -55,6 +56,16 @@ class Frames(C.Structure):
 _lib = None
 
 
+MAX_AUX = 32
+
+
+class EgomapConfig(C.Structure):
+    _fields_ = [("small_crop_px", C.c_int32), ("large_crop_px", C.c_int32), ("offset_for_cut", C.c_int32),
+                ("out_w", C.c_int32), ("out_h", C.c_int32), ("agent_radius_px", C.c_int32),
+                ("aux_bin_px", C.c_int32), ("n_aux", C.c_int32), ("aux_points", C.c_int32 * (2 * MAX_AUX)),
+                ("active_goal_color", C.c_uint8 * 3), ("arrow_color", C.c_uint8 * 3), ("pad", C.c_uint8 * 2)]
+
+
 def load():
     """Returns the loaded library; raises if it was not built (python semantic-search_amd/build.py)."""
     global _lib
@@ -79,6 +90,8 @@ def load():
     lib.ssmap_update_list.argtypes = [vp, i32, C.POINTER(vp)]
     lib.ssmap_profile_begin.argtypes = [vp, i32]
     lib.ssmap_profile_read.argtypes = [vp, vp, vp, vp]
+    lib.ssmap_set_egomap.argtypes = [vp, C.POINTER(EgomapConfig)]
+    lib.ssmap_ego_maps.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ssmap_last_error.restype = C.c_char_p
     lib.ssmap_version.restype = C.c_char_p
     for name in EXPORTS:

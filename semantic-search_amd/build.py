@@ -3,7 +3,7 @@
     python semantic-search_amd/build.py [--force]
 
 Output: semantic-search_amd/lib/libssmap.so (git-ignored; it travels with the tree to the
-GPU box).  geometry.hip, label.hip and engine.cpp are compiled with -ffp-contract=off: their
+GPU box).  geometry.hip, label.hip, ego.hip and engine.cpp are compiled with -ffp-contract=off: their
 float64 geometry has to round exactly like the CPU statement of the same formulas.
 """
 from __future__ import annotations
@@ -22,6 +22,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 SOURCES = [
     ("geometry.hip", ["-ffp-contract=off"]),
     ("label.hip", ["-ffp-contract=off"]),
+    ("ego.hip", ["-ffp-contract=off"]),
     ("fuse.hip", []),
     ("engine.cpp", ["-ffp-contract=off"]),
 ]

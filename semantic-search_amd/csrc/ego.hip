@@ -1,0 +1,169 @@
+// Egocentric observation maps (mapper.py:876-998): one thread per output pixel gathers straight
+// from the global maps -- crop, goal recolour, nearest-neighbour rotation, agent disk, auxiliary
+// squares, centre crop and resize are folded into the address computation of each tap, so no
+// intermediate image exists and no map leaves the GPU.
+//
+// The OpenCV steps are restated exactly as published for 4.x:
+//   warpAffine / INTER_NEAREST   inverse matrix in float64 (host), source coordinate =
+//                                (rint((M1 y + M2) 1024) + 512 + rint(M0 x 1024)) >> 10
+//   resize / INTER_AREA shrink   separable area table, float32, horizontal pass first
+//   resize / INTER_AREA enlarge  bilinear kernel with area-mode coefficients, 11-bit weights,
+//                                8-bit vertical pass
+//   resize / INTER_NEAREST       min(floor(d * scale), size - 1)
+// Compiled with -ffp-contract=off: the fixed-point coordinates and the float32 sums must round
+// like the separate multiply and add of the CPU code.
+#include "ssmap_internal.h"
+
+namespace ssmap {
+
+struct RGB {
+    float r, g, b;
+};
+
+// Rotated, overlaid image of one env at column X, row Y (both in [0, side)).
+struct EgoView {
+    const ssmap_env_maps *mp;
+    const EgoPose *pose;
+    const EgoTables *tab;
+    const uint8_t *aux_color;   // [n_aux][3] or nullptr (no auxiliary squares)
+    int side;
+};
+
+__device__ inline bool warp_source(const EgoView &ev, int X, int Y, int &cell, bool &in_map) {
+    const double *m = ev.pose->m;
+    const long long x0 = (long long)__builtin_rint((m[1] * (double)Y + m[2]) * 1024.0) + 512;
+    const long long y0 = (long long)__builtin_rint((m[4] * (double)Y + m[5]) * 1024.0) + 512;
+    const long long ad = (long long)__builtin_rint(m[0] * (double)X * 1024.0);
+    const long long bd = (long long)__builtin_rint(m[3] * (double)X * 1024.0);
+    long long xs = (x0 + ad) >> 10, ys = (y0 + bd) >> 10;
+    xs = xs < -32768 ? -32768 : (xs > 32767 ? 32767 : xs);
+    ys = ys < -32768 ? -32768 : (ys > 32767 ? 32767 : ys);
+    if (xs < 0 || xs >= ev.side || ys < 0 || ys >= ev.side) return false;   // constant border
+    const long long r = ev.pose->row0 + ys, c = ev.pose->col0 + xs;
+    in_map = r >= 0 && r < ev.mp->map_h && c >= 0 && c < ev.mp->map_w;      // zero padding outside
+    cell = in_map ? (int)(r * ev.mp->map_w + c) : 0;
+    return true;
+}
+
+__device__ inline void rot_pixel(const EgoView &ev, int X, int Y, int (&rgb)[3]) {
+    const EgoTables &t = *ev.tab;
+    const int org = t.origin;
+    // auxiliary squares are drawn last (mapper.py:934-935): the highest bin that covers the pixel wins
+    if (ev.aux_color) {
+        const int half = t.aux_half;
+        for (int j = t.n_aux - 1; j >= 0; --j) {
+            const int p0 = t.aux_points[2 * j] + org, p1 = t.aux_points[2 * j + 1] + org;
+            if (Y >= p0 - half && Y < p0 + half && X >= p1 - half && X < p1 + half) {
+                rgb[0] = ev.aux_color[3 * j]; rgb[1] = ev.aux_color[3 * j + 1]; rgb[2] = ev.aux_color[3 * j + 2];
+                return;
+            }
+        }
+    }
+    // agent disk (mapper.py:932, 1041-1051)
+    const int dy = Y - org, dx = X - org;
+    const int ady = dy < 0 ? -dy : dy;
+    if (ady <= t.agent_radius && t.agent_hw[ady] >= 0 && dx >= -t.agent_hw[ady] && dx <= t.agent_hw[ady]) {
+        rgb[0] = t.arrow_color[0]; rgb[1] = t.arrow_color[1]; rgb[2] = t.arrow_color[2];
+        return;
+    }
+    int cell;
+    bool in_map;
+    rgb[0] = rgb[1] = rgb[2] = 0;
+    if (!warp_source(ev, X, Y, cell, in_map) || !in_map) return;
+    if ((int)ev.mp->semantic_map[cell] == ev.pose->goal_id) {               // mapper.py:920
+        rgb[0] = t.active_goal_color[0]; rgb[1] = t.active_goal_color[1]; rgb[2] = t.active_goal_color[2];
+    } else {
+        const uint8_t *c = ev.mp->semantic_map_color + 3ll * cell;
+        rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
+    }
+}
+
+__device__ inline uint8_t round_u8(float v) {
+    const float r = __builtin_rintf(v);
+    return (uint8_t)(r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r));
+}
+
+// grid: (ceil(out_w * out_h / 256), 2 maps, envs of this launch)
+__global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0, const EgoTables *tables,
+                                                  uint8_t *ego_small, uint8_t *ego_large, float *unc_small,
+                                                  float *unc_large) {
+    const EgoTables &t = *tables;
+    const int which = blockIdx.y;                  // 0 = small crop, 1 = large crop
+    const int e = env0 + blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.out_w * t.out_h) return;
+    const int dy = i / t.out_w, dx = i - dy * t.out_w;
+    const EgoAxis &ax = t.axis[which][0], &ay = t.axis[which][1];
+    EgoView ev;
+    ev.mp = &v.envs[e].maps;
+    ev.pose = &pack.p[blockIdx.z];
+    ev.tab = tables;
+    ev.aux_color = ev.pose->has_aux ? ev.pose->aux_color : nullptr;
+    ev.side = t.side;
+    const int off = t.crop_off[which];             // centre crop of the rotated image (mapper.py:937-946)
+    uint8_t *dst = (which ? ego_large : ego_small) + ((int64_t)e * t.out_h * t.out_w + i) * 3;
+
+    if (t.mode[which] == kEgoArea) {
+        float sum[3] = {0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < ay.count[dy]; ++j) {
+            const int sy = t.tap_src[ay.first[dy] + j];
+            const float beta = t.tap_w[ay.first[dy] + j];
+            float buf[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < ax.count[dx]; ++k) {
+                const int sx = t.tap_src[ax.first[dx] + k];
+                const float alpha = t.tap_w[ax.first[dx] + k];
+                int rgb[3];
+                rot_pixel(ev, off + sx, off + sy, rgb);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) buf[c] = buf[c] + (float)rgb[c] * alpha;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum[c] = sum[c] + beta * buf[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = round_u8(sum[c]);
+    } else {
+        // bilinear kernel, area-mode coefficients: two source columns (the second pinned to the
+        // last column), two source rows (the second clipped), 11-bit weights
+        const int sx0 = ax.lin_src[dx], sy0 = ay.lin_src[dy];
+        const int sx1 = min(sx0 + 1, ax.ssize - 1), sy1 = min(sy0 + 1, ay.ssize - 1);
+        const int a0 = ax.lin_w0[dx], a1 = ax.lin_w1[dx], b0 = ay.lin_w0[dy], b1 = ay.lin_w1[dy];
+        int p00[3], p01[3], p10[3], p11[3];
+        rot_pixel(ev, off + sx0, off + sy0, p00);
+        rot_pixel(ev, off + sx1, off + sy0, p01);
+        rot_pixel(ev, off + sx0, off + sy1, p10);
+        rot_pixel(ev, off + sx1, off + sy1, p11);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int r0 = p00[c] * a0 + p01[c] * a1, r1 = p10[c] * a0 + p11[c] * a1;
+            const int o = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            dst[c] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+        }
+    }
+
+    float *udst = which ? unc_large : unc_small;
+    if (udst && ev.mp->unc_map) {
+        // nearest resize of the centre crop of the rotated uncertainty (mapper.py:959-994)
+        const int sx = min((int)floor((double)dx * ax.scale), ax.ssize - 1);
+        const int sy = min((int)floor((double)dy * ay.scale), ay.ssize - 1);
+        int cell;
+        bool in_map;
+        float u = -0.5f;                                                    // warp border
+        if (warp_source(ev, off + sx, off + sy, cell, in_map)) u = in_map ? ev.mp->unc_map[cell] : 0.0f;
+        udst[(int64_t)e * t.out_h * t.out_w + i] = u;
+    }
+}
+
+void launch_ego_maps(const View &v, const EgoPose *host_poses, const EgoTables *d_tables, const EgoTables &h_tables,
+                     uint8_t *ego_small, uint8_t *ego_large, float *unc_small, float *unc_large, hipStream_t s) {
+    const int n_pix = h_tables.out_w * h_tables.out_h;
+    for (int env0 = 0; env0 < v.E; env0 += kEgoPack) {
+        const int n = v.E - env0 < kEgoPack ? v.E - env0 : kEgoPack;
+        EgoPack pack;
+        for (int i = 0; i < n; ++i) pack.p[i] = host_poses[env0 + i];
+        hipLaunchKernelGGL(k_ego_maps, dim3((n_pix + 255) / 256, 2, n), dim3(256), 0, s, v, pack, env0, d_tables,
+                           ego_small, ego_large, unc_small, unc_large);
+    }
+}
+
+}  // namespace ssmap

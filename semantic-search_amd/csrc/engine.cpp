@@ -115,6 +115,10 @@ struct ssmap_engine {
     bool have_params = false, have_schema = false, have_palette = false;
     Quat flip_cam{};
     int device = 0;
+    // egocentric observation maps (ssmap_set_egomap / ssmap_ego_maps)
+    EgoTables *d_ego = nullptr;
+    std::vector<EgoTables> h_ego;          // one element once configured
+    std::vector<EgoPose> h_ego_poses;
     // optional per-stage timing (ssmap_profile_begin / ssmap_profile_read)
     std::vector<hipEvent_t> prof_events;   // kProfMarks per recorded step
     int prof_capacity = 0, prof_steps = 0;
@@ -135,7 +139,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
-    hipFree(eng->d_disk); hipFree(eng->d_palette);
+    hipFree(eng->d_disk); hipFree(eng->d_palette); hipFree(eng->d_ego);
     for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
     for (int i = 0; i < kPoseRing; ++i) {
         if (eng->h_ring[i]) hipHostFree(eng->h_ring[i]);
@@ -322,6 +326,149 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
     const uint32_t zero = 0;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(hipMemcpy(eng->view.overlay_count[i] + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+    return SSMAP_OK;
+}
+
+// One axis of one of the two resizes, the way OpenCV's resize() sets it up (4.x resize.cpp):
+// inv = dst / src, scale = 1 / inv; area table (computeResizeAreaTab) when shrinking, bilinear
+// area-mode weights otherwise.
+static bool build_ego_axis(EgoTables &t, EgoAxis &ax, int ssize, int dsize, int mode, bool horizontal, int &pool) {
+    const double inv = (double)dsize / ssize, scale = 1.0 / inv;
+    ax.ssize = ssize;
+    ax.scale = scale;
+    for (int d = 0; d < dsize; ++d) {
+        ax.first[d] = pool;
+        ax.count[d] = 0;
+        if (mode == kEgoArea) {
+            const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+            const double cell = std::min(scale, ssize - fsx1);
+            int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+            sx2 = std::min(sx2, ssize - 1);
+            sx1 = std::min(sx1, sx2);
+            auto push = [&](int si, double w) {
+                if (pool >= kEgoTapPool) return false;
+                t.tap_src[pool] = si;
+                t.tap_w[pool] = (float)w;
+                ++pool;
+                ++ax.count[d];
+                return true;
+            };
+            if (sx1 - fsx1 > 1e-3 && !push(sx1 - 1, (sx1 - fsx1) / cell)) return false;
+            for (int sx = sx1; sx < sx2; ++sx)
+                if (!push(sx, 1.0 / cell)) return false;
+            if (fsx2 - sx2 > 1e-3 && !push(sx2, std::min(std::min(fsx2 - sx2, 1.0), cell) / cell)) return false;
+        } else {
+            int sx = (int)std::floor(d * scale);
+            float fx = (float)((d + 1) - (sx + 1) * inv);
+            fx = fx <= 0 ? 0.f : fx - std::floor(fx);
+            if (horizontal && sx < 0) { fx = 0.f; sx = 0; }
+            if (horizontal && sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+            ax.lin_src[d] = sx;
+            auto sat_short = [](float v) { const long r = std::lrintf(v); return (int)std::max(-32768l, std::min(32767l, r)); };
+            ax.lin_w0[d] = sat_short((1.f - fx) * 2048.f);
+            ax.lin_w1[d] = sat_short(fx * 2048.f);
+        }
+    }
+    return true;
+}
+
+int ssmap_set_egomap(ssmap_engine *eng, const ssmap_egomap_config *cfg) {
+    if (!eng || !cfg) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    const ssmap_egomap_config &c = *cfg;
+    if (c.small_crop_px < 1 || c.large_crop_px < c.small_crop_px || c.offset_for_cut < 0 ||
+        c.large_crop_px + c.offset_for_cut > 32767)
+        return fail(SSMAP_ERR_INVALID_ARG, "ego-map crop sizes out of range");
+    if (c.out_w < 1 || c.out_h < 1 || c.out_w > kEgoMaxOut || c.out_h > kEgoMaxOut)
+        return fail(SSMAP_ERR_INVALID_ARG, "egomap_size must be within 256 x 256");
+    if (c.agent_radius_px < 0 || c.agent_radius_px > kEgoMaxRadius || c.n_aux < 0 || c.n_aux > SSMAP_MAX_AUX)
+        return fail(SSMAP_ERR_INVALID_ARG, "agent radius or auxiliary bins out of range");
+    eng->h_ego.assign(1, EgoTables{});
+    EgoTables &t = eng->h_ego[0];
+    t.side = c.large_crop_px + c.offset_for_cut;
+    t.origin = (int)(float)(t.side / 2.0);
+    t.out_w = c.out_w; t.out_h = c.out_h;
+    t.agent_radius = c.agent_radius_px;
+    t.aux_half = c.aux_bin_px / 2;
+    t.n_aux = c.n_aux;
+    const std::vector<int32_t> hw = disk_halfwidths(c.agent_radius_px);
+    for (int i = 0; i <= c.agent_radius_px; ++i) t.agent_hw[i] = hw[i];
+    memcpy(t.aux_points, c.aux_points, sizeof(int32_t) * 2 * c.n_aux);
+    memcpy(t.active_goal_color, c.active_goal_color, 3);
+    memcpy(t.arrow_color, c.arrow_color, 3);
+    int pool = 0;
+    const int crop[2] = {c.small_crop_px, c.large_crop_px};
+    for (int w = 0; w < 2; ++w) {
+        t.crop_off[w] = (int)(t.side / 2.0 - crop[w] / 2.0);
+        const double sx = 1.0 / ((double)c.out_w / crop[w]), sy = 1.0 / ((double)c.out_h / crop[w]);
+        if (sx >= 1 && sy >= 1) {
+            const double eps = 2.220446049250313e-16;
+            if (std::fabs(sx - (int)sx) < eps && std::fabs(sy - (int)sy) < eps) {
+                eng->h_ego.clear();
+                return fail(SSMAP_ERR_UNSUPPORTED, "ego-map crops that are an integer multiple of egomap_size are not built "
+                                                   "(OpenCV takes its integer-factor area path there)");
+            }
+            t.mode[w] = kEgoArea;
+        } else {
+            t.mode[w] = kEgoLinear;
+        }
+        if (!build_ego_axis(t, t.axis[w][0], crop[w], c.out_w, t.mode[w], true, pool) ||
+            !build_ego_axis(t, t.axis[w][1], crop[w], c.out_h, t.mode[w], false, pool)) {
+            eng->h_ego.clear();
+            return fail(SSMAP_ERR_UNSUPPORTED, "ego-map crops too large for the resize tables");
+        }
+    }
+    if (!eng->d_ego) {
+        int rc = dev_alloc(&eng->d_ego, (size_t)1);
+        if (rc != SSMAP_OK) return rc;
+    }
+    HIP_TRY(hipMemcpy(eng->d_ego, &t, sizeof(EgoTables), hipMemcpyHostToDevice));
+    return SSMAP_OK;
+}
+
+int ssmap_ego_maps(ssmap_engine *eng, const double *agent_pose, const int32_t *goal_sem_id,
+                   const uint8_t *aux_color, uint8_t *ego_small, uint8_t *ego_large,
+                   float *unc_small, float *unc_large, void *stream_v) {
+    if (!eng || !agent_pose || !goal_sem_id || !ego_small || !ego_large)
+        return fail(SSMAP_ERR_INVALID_ARG, "agent_pose, goal_sem_id, ego_small and ego_large are required");
+    if (eng->h_ego.empty()) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_egomap was not called");
+    for (const EnvState &s : eng->envs)
+        if (!s.bound) return fail(SSMAP_ERR_NOT_READY, "an env has no maps bound (ssmap_bind_env)");
+    const ssmap_config &c = eng->cfg;
+    const EgoTables &t = eng->h_ego[0];
+    eng->h_ego_poses.assign(c.n_envs, EgoPose{});
+    for (int e = 0; e < c.n_envs; ++e) {
+        const double *ag = agent_pose + 7 * e;
+        const ssmap_env_maps &mp = eng->envs[e].maps;
+        EgoPose &p = eng->h_ego_poses[e];
+        // heading = R(agent rotation) (0,0,1); phi = atan2(heading z, heading x) (mapper.py:885-890)
+        double R[9];
+        qmatrix(Quat{ag[3], ag[4], ag[5], ag[6]}, R);
+        const double phi = std::atan2(R[8], R[2]);
+        // getRotationMatrix2D((side/2, side/2), deg(phi) + 90, 1) and warpAffine's inversion
+        double angle = phi * (180.0 / M_PI) + 90;
+        angle *= M_PI / 180;
+        const double alpha = std::cos(angle), beta = std::sin(angle);
+        const double cx = (double)(float)(t.side / 2.0), cy = cx;
+        double m[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+        double D = m[0] * m[4] - m[1] * m[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = m[4] * D, A22 = m[0] * D;
+        m[0] = A11; m[1] *= -D; m[3] *= -D; m[4] = A22;
+        const double b1 = -m[0] * m[2] - m[1] * m[5], b2 = -m[3] * m[2] - m[4] * m[5];
+        m[2] = b1; m[5] = b2;
+        memcpy(p.m, m, sizeof(m));
+        // crop window of side t.side centred on the agent's cell (mapper.py:891, 904-911, 1000-1004)
+        const double pr = std::floor((ag[2] - mp.lower[2]) / c.pixel2meter);
+        const double pc = std::floor((ag[0] - mp.lower[0]) / c.pixel2meter);
+        p.row0 = clamp_cell(pr - t.side / 2.0);
+        p.col0 = clamp_cell(pc - t.side / 2.0);
+        p.goal_id = goal_sem_id[e];
+        p.has_aux = aux_color ? 1 : 0;
+        if (aux_color) memcpy(p.aux_color, aux_color + (size_t)e * t.n_aux * 3, (size_t)t.n_aux * 3);
+    }
+    launch_ego_maps(eng->view, eng->h_ego_poses.data(), eng->d_ego, t, ego_small, ego_large, unc_small, unc_large,
+                    reinterpret_cast<hipStream_t>(stream_v));
+    HIP_TRY(hipGetLastError());
     return SSMAP_OK;
 }
 

@@ -121,6 +121,44 @@ __host__ __device__ inline double unorder_f64(unsigned long long k) {
     return __builtin_bit_cast(double, (long long)b);
 }
 
+// ---- egocentric observation maps (mapper.py:876-998)
+constexpr int kEgoMaxOut = 256;        // output side at most
+constexpr int kEgoTapPool = 16384;     // area-table entries of both crops and both axes
+constexpr int kEgoMaxRadius = 63;      // agent disk radius at most
+constexpr int kEgoPack = 16;           // envs per launch (their poses travel as a kernel argument)
+constexpr int kEgoArea = 0, kEgoLinear = 1;
+
+// Per env and call: inverse rotation (OpenCV's inverted 2x3 matrix), crop origin, goal.
+struct EgoPose {
+    double m[6];
+    int32_t row0, col0;    // global cell of pixel (0, 0) of the crop (may lie outside the map)
+    int32_t goal_id;
+    int32_t has_aux;
+    uint8_t aux_color[3 * SSMAP_MAX_AUX];   // colour of each auxiliary-angle square
+};
+struct EgoPack {
+    EgoPose p[kEgoPack];
+};
+// One axis of one resize: either an area table (shrinking) or bilinear area-mode weights.
+struct EgoAxis {
+    int32_t ssize;
+    int32_t pad;
+    double scale;                       // 1 / (dsize / ssize), as OpenCV derives it
+    int32_t first[kEgoMaxOut], count[kEgoMaxOut];                        // area: slice of the tap pool
+    int32_t lin_src[kEgoMaxOut], lin_w0[kEgoMaxOut], lin_w1[kEgoMaxOut]; // enlarging
+};
+struct EgoTables {
+    int32_t side, origin, out_w, out_h;
+    int32_t crop_off[2], mode[2];       // [0] small crop, [1] large crop
+    int32_t agent_radius, aux_half, n_aux, pad;
+    int32_t agent_hw[kEgoMaxRadius + 1];
+    int32_t aux_points[2 * SSMAP_MAX_AUX];
+    uint8_t active_goal_color[4], arrow_color[4];
+    EgoAxis axis[2][2];                 // [crop][0 = x, 1 = y]
+    int32_t tap_src[kEgoTapPool];
+    float tap_w[kEgoTapPool];
+};
+
 // launchers (defined in the .hip files)
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s);
 void launch_winners(const View &v, hipStream_t s);
@@ -129,5 +167,7 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_found(const View &v, hipStream_t s);
+void launch_ego_maps(const View &v, const EgoPose *host_poses, const EgoTables *d_tables, const EgoTables &h_tables,
+                     uint8_t *ego_small, uint8_t *ego_large, float *unc_small, float *unc_large, hipStream_t s);
 
 }  // namespace ssmap

@@ -136,6 +136,62 @@ class MapEngine:
         self.map_bounds: list[Optional[np.ndarray]] = [None] * self.n_envs
         self._keep = None
 
+    # ------------------------------------------------------------------ egocentric maps
+    def set_egomap(self, egomap_small_side_m: float = 3.0, egomap_large_side_m: float = 10.0,
+                   egomap_size=(128, 128), agent_draw_radius_m: float = 0.1, aux_num_bins: int = 12,
+                   aux_radius_m: float = 0.4, aux_bin_m: float = 0.15, offset_for_cut: int = 150):
+        """The ego-map constants the reference derives in its constructor (mapper.py:77-109)."""
+        p2m = self.pixel2meter
+        cfg = _capi.EgomapConfig()
+        cfg.small_crop_px = int(egomap_small_side_m / p2m)
+        cfg.large_crop_px = int(egomap_large_side_m / p2m)
+        cfg.offset_for_cut = int(offset_for_cut)
+        cfg.out_w, cfg.out_h = int(egomap_size[0]), int(egomap_size[1])
+        cfg.agent_radius_px = int(agent_draw_radius_m / p2m)
+        cfg.aux_bin_px = int(aux_bin_m / p2m)
+        cfg.n_aux = int(aux_num_bins)
+        radius_px = int(aux_radius_m / p2m)
+        pts = [-np.array((radius_px * np.cos(np.deg2rad(d)), radius_px * np.sin(np.deg2rad(d))))
+               for d in np.arange(0, 360, 360 / aux_num_bins)]
+        pts = np.array(pts, dtype=np.int32).reshape(-1)            # truncation, like the reference's cast
+        for i, vv in enumerate(pts):
+            cfg.aux_points[i] = int(vv)
+        n = self.num_semantic_classes
+        for i in range(3):
+            cfg.active_goal_color[i] = int(self.color_pallete[n][i])
+            cfg.arrow_color[i] = int(self.color_pallete[n + 2][i])
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ssmap_set_egomap(self._h, C.byref(cfg)))
+        self._ego_shape = (cfg.out_h, cfg.out_w)
+        self._ego_bins = cfg.n_aux
+
+    def ego_maps(self, agent_pose, goal_sem_ids, aux_angle_onehot=None):
+        """`SemanticMapper.ego_map` (mapper.py:876-998) for every env from the maps as they stand.
+        Returns (ego_small, ego_large [E][h][w][3] u8, unc_small, unc_large [E][h][w] f32 or None)."""
+        if getattr(self, "_ego_shape", None) is None:
+            self.set_egomap()
+        h, w = self._ego_shape
+        ag = np.ascontiguousarray(agent_pose, dtype=np.float64).reshape(self.n_envs, 7)
+        goals = np.ascontiguousarray(goal_sem_ids, dtype=np.int32).reshape(self.n_envs)
+        aux = None
+        if aux_angle_onehot is not None:
+            onehot = np.asarray(aux_angle_onehot).reshape(self.n_envs, self._ego_bins)
+            aux = np.ascontiguousarray(
+                (np.array([255, 255, 255], dtype=np.uint8)[None, None, :] * onehot[:, :, None]).astype(np.uint8))
+        small = torch.empty((self.n_envs, h, w, 3), dtype=torch.uint8, device=self.device)
+        large = torch.empty_like(small)
+        unc_s = unc_l = None
+        if self.probablistic_mapping:
+            unc_s = torch.empty((self.n_envs, h, w), dtype=torch.float32, device=self.device)
+            unc_l = torch.empty_like(unc_s)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ssmap_ego_maps(
+                self._h, ag.ctypes.data, goals.ctypes.data, aux.ctypes.data if aux is not None else None,
+                small.data_ptr(), large.data_ptr(), unc_s.data_ptr() if unc_s is not None else None,
+                unc_l.data_ptr() if unc_l is not None else None,
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return small, large, unc_s, unc_l
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.ssmap_destroy(self._h)

@@ -6,8 +6,7 @@ sem_objnav/obj_nav/mapper.py:48-269, so the callers (`MappingObjNavEnv`, env.py:
 reference class.  Observations arrive as numpy arrays (one frame), are copied to the GPU,
 fused there, and the map arrays are copied back only when a caller reads them.
 
-Not built yet (returned as blank arrays of the reference's shapes): the ego-centric crops of
-`ego_map` (mapper.py:876-998), the path overlay (mapper.py:822-833) and the "stubborn" rule.
+Not built yet: the path overlay (mapper.py:822-833) and the "stubborn" rule.
 """
 from __future__ import annotations
 
@@ -115,6 +114,10 @@ class SemanticMapper:
         self.egomap_size = egomap_size
         self.egomap_small_crop = [int(egomap_small_side_m / pixel2meter)] * 2
         self.egomap_large_crop = [int(egomap_large_side_m / pixel2meter)] * 2
+        self.offset_for_cut = 150
+        self.aux_bin_px = int(aux_bin_m / pixel2meter)
+        self._ego_cfg = dict(egomap_small_side_m=egomap_small_side_m, egomap_large_side_m=egomap_large_side_m,
+                             agent_draw_radius_m=agent_draw_radius_m, aux_radius_m=aux_radius_m, aux_bin_m=aux_bin_m)
         self.path_width_px = int(path_width_m / pixel2meter)
         self.agent_radius_px = int(agent_draw_radius_m / pixel2meter)
         self.color_pallete = _engine.colormap(num_semantic_classes + 3)
@@ -175,6 +178,9 @@ class SemanticMapper:
                 height_cutoff_m=self.height_cutoff_m, probablistic_mapping=self.probablistic_mapping,
                 prob_aggregate=self.prob_aggregate, seg_model_n_classes=self.sem_model_n_classes,
                 max_map_hw=(rows, cols), success_dist_m=self.found_dist_m, device=self._device)
+            eng.set_egomap(self._ego_cfg["egomap_small_side_m"], self._ego_cfg["egomap_large_side_m"],
+                           self.egomap_size, self._ego_cfg["agent_draw_radius_m"], self.aux_bin_number,
+                           self._ego_cfg["aux_radius_m"], self._ego_cfg["aux_bin_m"], self.offset_for_cut)
             self._engine, self._engine_key = eng, key
             self._bound = False
             self._schema_sent = False
@@ -250,10 +256,10 @@ class SemanticMapper:
         is_found = True if found[0] else None
         if is_found:
             self.found_idx = self._disk_indices(self.prev_pos_px)
-        size = tuple(self.egomap_size)
-        blank = np.zeros((size[1], size[0], 3), dtype=np.uint8)
-        unc = np.full((size[1], size[0]), -0.5, dtype=np.float32) if self.probablistic_mapping else None
-        ego = (blank, blank.copy(), unc, None if unc is None else unc.copy())
+        small, large, unc_s, unc_l = eng.ego_maps(np.asarray(obs["agent_position_and_rotation"])[None], [goal_id],
+                                                  None if auxillary_angle is None else np.asarray(auxillary_angle)[None])
+        ego = (small[0].cpu().numpy(), large[0].cpu().numpy(),
+               None if unc_s is None else unc_s[0].cpu().numpy(), None if unc_l is None else unc_l[0].cpu().numpy())
         return ego, is_found
 
     def _disk_indices(self, center):

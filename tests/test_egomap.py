@@ -1,0 +1,150 @@
+"""Egocentric observation maps (mapper.py:876-998).
+
+PARITY UNPINNED: the reference builds them with OpenCV, which is absent from the image, and holds
+no vectors.  The CPU tests check the restated primitives (oracle/egomap_oracle.py) against
+properties the published algorithms have; the GPU tests demand that the HIP kernel equals that
+restatement bit for bit (uint8 colours, float32 uncertainties)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import egomap_oracle as eo
+from oracle import mapper_oracle as mo
+from tests import scenes
+
+
+def _yaw_quat(yaw):
+    return np.array([math.cos(yaw / 2), 0.0, math.sin(yaw / 2), 0.0])      # w, x, y, z: rotation about y
+
+
+def test_area_table_weights_sum_to_one():
+    for ssize, dsize in ((333, 128), (500, 128), (200, 128), (129, 128)):
+        tab = eo.area_table(ssize, dsize)
+        sums = np.zeros(dsize)
+        for d, s, w in tab:
+            assert 0 <= s < ssize
+            sums[d] += float(w)
+        assert np.allclose(sums, 1.0, atol=1e-6)
+
+
+def test_resizes_keep_constant_images_constant():
+    for side in (100, 333):
+        img = np.full((side, side, 3), 137, dtype=np.uint8)
+        assert (eo.resize_area_u8(img, (128, 128)) == 137).all()
+    unc = np.full((100, 100), 0.25, dtype=np.float32)
+    assert (eo.resize_nearest(unc, (128, 128)) == np.float32(0.25)).all()
+
+
+def test_enlarging_area_mode_repeats_source_pixels_between_boundaries():
+    """100 -> 128: destination pixels that lie inside one source pixel copy it exactly."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (100, 100, 3)).astype(np.uint8)
+    out = eo.resize_area_enlarge_u8(img, (128, 128))
+    assert out.shape == (128, 128, 3)
+    assert np.array_equal(out[0, 0], img[0, 0])
+    assert np.array_equal(out[127, 127], img[99, 99])
+
+
+def test_warp_by_zero_angle_is_the_identity_and_quarter_turn_rotates():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (41, 41, 3)).astype(np.uint8)
+    M = eo.rotation_matrix_2d((20.5, 20.5), 0.0)
+    assert np.array_equal(eo.warp_affine_nearest(img, M, (41, 41), (0, 0, 0)), img)
+    M = eo.rotation_matrix_2d((20.0, 20.0), 90.0)
+    out = eo.warp_affine_nearest(img, M, (41, 41), (0, 0, 0))
+    assert np.array_equal(out, np.rot90(img, 1))            # positive angle = counter-clockwise
+
+
+def test_crop_pads_with_zeros_outside_the_map():
+    img = np.arange(25, dtype=np.uint32).reshape(5, 5) + 1
+    out = eo.crop_fn(img, np.array([0, 4]), (4, 4))
+    assert out.shape == (4, 4)
+    assert out[0, 0] == 0 and out[2, 0] == img[0, 2]
+
+
+def _random_maps(rng, rows, cols, palette, goal):
+    sem = rng.integers(0, 3, (rows, cols)).astype(np.uint32)
+    for _ in range(25):
+        r, c = rng.integers(0, rows), rng.integers(0, cols)
+        sem[r:r + rng.integers(2, 15), c:c + rng.integers(2, 15)] = rng.integers(3, 9)
+    color = palette[sem]
+    unc = rng.random((rows, cols, 1)).astype(np.float32)
+    return sem, color, unc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob,large_side_m,with_aux", [(True, 10.0, True), (False, 10.0, False), (True, 15.0, False)])
+def test_engine_ego_maps_equal_the_restatement(prob, large_side_m, with_aux):
+    import torch
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(11)
+    bounds = [np.array([0.0, -0.2, 0.0, 9.0, 2.5, 7.5]), np.array([-2.0, 0.0, 1.0, 4.0, 2.5, 13.0]),
+              np.array([0.0, 0.0, 0.0, 14.39, 3.0, 14.39])]
+    n = len(bounds)
+    eng = ssa.MapEngine(n, (48, 64), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                        probablistic_mapping=prob, prob_aggregate="height_map_argmax", max_map_hw=(480, 480))
+    eng.set_egomap(egomap_large_side_m=large_side_m)
+    palette = eng.color_pallete
+    host = []
+    for e in range(n):
+        maps = eng.reset_env(e, bounds[e])
+        rows, cols = maps["semantic_map"].shape
+        sem, color, unc = _random_maps(rng, rows, cols, palette, 3 + e)
+        maps["semantic_map"].copy_(torch.from_numpy(sem.view(np.int32)))
+        maps["semantic_map_color"].copy_(torch.from_numpy(color))
+        if prob:
+            maps["unc_map"].copy_(torch.from_numpy(unc))
+        host.append((sem, color, unc if prob else None))
+    for trial in range(3):
+        poses, goals = [], []
+        for e in range(n):
+            b = bounds[e]
+            # inside the map, at its edge, and outside of it
+            fx, fz = [(0.5, 0.5), (0.02, 0.97), (-0.05, 0.4)][(trial + e) % 3]
+            pos = np.array([b[0] + fx * (b[3] - b[0]), 0.1, b[2] + fz * (b[5] - b[2])])
+            poses.append(np.concatenate([pos, _yaw_quat(rng.uniform(-math.pi, math.pi))]))
+            goals.append(3 + (e + trial) % 6)
+        aux = None
+        if with_aux:
+            aux = np.zeros((n, 12), dtype=np.float32)
+            aux[np.arange(n), rng.integers(0, 12, n)] = 1.0
+            aux[0, 5] = 0.5                                     # not one-hot: colour 127
+        small, large, unc_s, unc_l = eng.ego_maps(np.stack(poses), goals, aux)
+        torch.cuda.synchronize()
+        for e in range(n):
+            sem, color, unc = host[e]
+            want = eo.ego_map(sem, color, unc, poses[e][:3], poses[e][3:], bounds[e][:3], goals[e], palette,
+                              aux_angle_onehot=None if aux is None else aux[e], egomap_large_side_m=large_side_m)
+            assert np.array_equal(small[e].cpu().numpy(), want[0]), (trial, e, "small")
+            assert np.array_equal(large[e].cpu().numpy(), want[1]), (trial, e, "large")
+            if prob:
+                assert np.array_equal(unc_s[e].cpu().numpy(), want[2]), (trial, e, "unc small")
+                assert np.array_equal(unc_l[e].cpu().numpy(), want[3]), (trial, e, "unc large")
+            else:
+                assert unc_s is None and want[2] is None
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_mapper_update_map_returns_ego_maps():
+    """The drop-in class returns the four ego arrays with the reference's shapes and dtypes and
+    they show the freshly fused map (not blank)."""
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(2)
+    lut = scenes.small_lut(8)
+    m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                           probablistic_mapping=True, prob_aggregate="height_map_argmax", seg_model_n_classes=8)
+    m.map_seg_to_schema = lambda ids: lut[ids]
+    m.reset(np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5]))
+    agent, cam = scenes.make_pose(1.5, 0.0, 1.2, 0.8)
+    frame = scenes.room_frame(rng, 96, 128, 8, 1.0, cam, lut=lut)
+    ego, found = m.update_map(scenes.make_obs(frame, agent, cam, goal_index=0), np.eye(12, dtype=np.float32)[3])
+    small, large, unc_s, unc_l = ego
+    assert small.shape == (128, 128, 3) and small.dtype == np.uint8 and large.shape == (128, 128, 3)
+    assert unc_s.shape == (128, 128) and unc_s.dtype == np.float32 and unc_l.shape == (128, 128)
+    assert small.any() and large.any()
+    want = eo.ego_map(m.semantic_map, m.semantic_map_color, m.unc_map, agent[:3], agent[3:], m.map_bounds[:3],
+                      int(m.goal2sem_id[0]), m.color_pallete, aux_angle_onehot=np.eye(12, dtype=np.float32)[3])
+    assert np.array_equal(small, want[0]) and np.array_equal(large, want[1])
+    assert np.array_equal(unc_s, want[2]) and np.array_equal(unc_l, want[3])

@@ -135,7 +135,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec_h); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
+    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec_h); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wflag); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -203,7 +203,9 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&v.part_start, (size_t)v.E * (kMaxParts + 1)));
     if (prob_rule) {
         TRY_ALLOC(dev_alloc(&v.target, EN));
-        TRY_ALLOC(dev_alloc(&v.wprob, EN * (size_t)v.C));
+        TRY_ALLOC(dev_alloc(&v.wflag, EN));
+        v.wprob_stride = v.C;   // padding the rows to whole cache lines measured slower
+        TRY_ALLOC(dev_alloc(&v.wprob, EN * (size_t)v.wprob_stride));
     }
     TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
     TRY_ALLOC(dev_alloc(&v.wheight, EN));

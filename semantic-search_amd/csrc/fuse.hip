@@ -83,13 +83,16 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
 
-    // asked for first: the answer is needed last, after the softmax arithmetic
-    int slot = -1;
-    if (MODE != 0 && active) slot = __builtin_nontemporal_load(v.target + fbase + pix);
+    // asked for first: one byte per pixel says whether it owns a map cell this step
+    uint8_t owns = 0;
+    if (MODE != 0 && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
         x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+    // only the few owners fetch their list slot (needed last, after the softmax arithmetic)
+    int slot = -1;
+    if (MODE != 0 && owns) slot = v.target[fbase + pix];
 
     if (a.from_logits) {
         // no implicit fused multiply-add in here: x k - max(x k) must be exactly 0 at the max
@@ -158,15 +161,17 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
         const int rows = min(kRows, total - r0);
         if (CT % 4 == 0) {
             constexpr int Q = CT / 4;
-            for (int j = t; j < rows * Q; j += kTile) {
-                const int k = j / Q, q = j - k * Q;
-                const float4 val = *reinterpret_cast<const float4 *>(&stage.row[k][4 * q]);
-                *reinterpret_cast<float4 *>(v.wprob + (fbase + stage.slot[k]) * CT + 4 * q) = val;
+            const int qs = v.wprob_stride / 4;     // rows may be padded to whole cache lines
+            for (int j = t; j < rows * qs; j += kTile) {
+                const int k = j / qs, q = j - k * qs;
+                float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (q < Q) val = *reinterpret_cast<const float4 *>(&stage.row[k][4 * q]);
+                *reinterpret_cast<float4 *>(v.wprob + (fbase + stage.slot[k]) * v.wprob_stride + 4 * q) = val;
             }
         } else {
             for (int j = t; j < rows * CT; j += kTile) {
                 const int k = j / CT, c = j - k * CT;
-                v.wprob[(fbase + stage.slot[k]) * CT + c] = stage.row[k][c];
+                v.wprob[(fbase + stage.slot[k]) * v.wprob_stride + c] = stage.row[k][c];
             }
         }
         __syncthreads();
@@ -236,9 +241,9 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
         }
     }
     if (MODE == 0) return;
-    const int slot = active ? v.target[fbase + pix] : -1;
+    const int slot = (active && v.wflag[fbase + pix]) ? v.target[fbase + pix] : -1;
     if (slot >= 0) {
-        float *dst = v.wprob + (fbase + slot) * C;
+        float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
         for (int c = 0; c < C; ++c) dst[c] = col[c * kStride];
     }
 }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                 for (int k = 0; k < K; ++k) { mv[b][k] = 0.0f; p[b][k] = 0.0f; }
                 if (live[b]) {
                     const float *mrow = mp.prob_map + (int64_t)cell[b] * C;
-                    const float *prow = v.wprob + (fbase + i) * C;
+                    const float *prow = v.wprob + (fbase + i) * v.wprob_stride;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int c = V * (sub + 16 * k);

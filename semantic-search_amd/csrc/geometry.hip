@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
         unsigned long long *hp = v.horder + fbase + i0;
         *reinterpret_cast<ulonglong2 *>(hp) = make_ulonglong2(hk[0], hk[1]);
         *reinterpret_cast<ulonglong2 *>(hp + 2) = make_ulonglong2(hk[2], hk[3]);
-        if (write_target) *reinterpret_cast<int4 *>(v.target + fbase + i0) = make_int4(-1, -1, -1, -1);
+        if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
     }
 
     // block reduction of the bbox, the lowest invalid pixel and the error bits
@@ -594,7 +594,7 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
             if (write_list) {
                 const unsigned pos = s_base + s_cnt[it * kWaves + wave] +
                                      (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull));
-                if (write_target) v.target[fbase + pix] = (int)pos;
+                if (write_target) { v.target[fbase + pix] = (int)pos; v.wflag[fbase + pix] = 1; }
                 int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
                 const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
                 *out = make_int2((int)word, cell);
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(1024) void k_resolve_wrapped(View v, int write_targ
         const int owner = max(max(qs.x, qs.y), max(qs.z, qs.w));
         if (owner != pix + 1) {
             list[i].x = (int)((uint32_t)pc.x | kLostBit);
-            if (write_target) v.target[fbase + pix] = -1;
+            if (write_target) v.wflag[fbase + pix] = 0;
         }
     }
 }

@@ -87,8 +87,10 @@ struct View {
     int32_t rec_packed;
     unsigned int *bin_cnt;     // [E][N/1024][kMaxParts] per-block table counts, then record bases
     unsigned int *part_start;  // [E][kMaxParts+1] first record of each table
-    int32_t *target;           // [E][N] slot of this pixel in the frame's update list, or -1
-    float *wprob;              // [E][N][C] class probabilities of the update pixels, row = list slot
+    int32_t *target;           // [E][N] slot in the frame's update list, valid where wflag is set
+    uint8_t *wflag;            // [E][N] 1 = this pixel owns a map cell this step (cleared by the geometry kernel)
+    float *wprob;              // [E][N][wprob_stride] class probabilities of the update pixels, row = list slot
+    int32_t wprob_stride;      // floats per row (>= C)
     int32_t *winners;          // [E][N][2] update list: (pixel word, cell) pairs in cell order per table
     unsigned long long *wheight;  // [E][N] height image of each list slot's pixel
     int32_t *quad;             // [E][maxHm*maxWm][4] 1 + update pixel of each index-sign quadrant that

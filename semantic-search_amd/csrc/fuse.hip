@@ -462,8 +462,14 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
     // the register kernels address a whole frame with 32-bit buffer offsets
     if ((int64_t)v.C * v.N * 4 < (1ll << 31)) {
         switch (v.C) {
+            // the class counts of the reference's segmentation heads (EMSANet 8/33/37/40/53/81,
+            // SegFormer ADE20k 150); any other count streams through LDS below
+            case 8: launch_reg<8>(mode, s, v, a); return;
+            case 33: launch_reg<33>(mode, s, v, a); return;
             case 37: launch_reg<37>(mode, s, v, a); return;
             case 40: launch_reg<40>(mode, s, v, a); return;
+            case 53: launch_reg<53>(mode, s, v, a); return;
+            case 81: launch_reg<81>(mode, s, v, a); return;
             case 150: launch_reg<150>(mode, s, v, a); return;
             default: break;
         }

@@ -39,7 +39,7 @@ def _top2_margin(vectors):
     return (srt[..., -1] - srt[..., -2]) / np.maximum(np.abs(srt[..., -1]), 1e-30)
 
 
-@pytest.mark.parametrize("n_classes,temperature", [(40, 3.2), (150, 2.5), (12, 1.0)])
+@pytest.mark.parametrize("n_classes,temperature", [(40, 3.2), (150, 2.5), (12, 1.0), (53, 2.0), (8, 1.0)])
 def test_stage1_matches_oracle(n_classes, temperature):
     import semantic_search_amd as ssa
     h, w = 120, 160

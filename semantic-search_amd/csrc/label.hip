@@ -11,7 +11,7 @@
 
 namespace ssmap {
 
-constexpr int kListBlocks = 64;      // blocks per env for list / bbox sweeps
+constexpr int kListBlocks = 128;     // blocks per env for list / bbox sweeps (one cell per thread for typical frames)
 constexpr int kGdLost = 0x80;        // goal_decay local map: pixel lost its wrapped cell to a later one
 
 __device__ inline int occupancy_override(int id, float h, int use_height, int n_schema) {
@@ -72,9 +72,25 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
         if (pw & kLostBit) continue;
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
-        const float h = raise_height(v, mp, pb, fbase, pix, cell);
+        // every gather of this cell is issued before the first store (the stores could alias the
+        // loads as far as the compiler knows, and would otherwise chain the round trips)
+        const float h_old = mp.height_map[cell];
+        const unsigned long long hk = v.horder[fbase + pix];
         int id = semantic[fbase + pix];
         const int raw = id;
+        const int gtv = v.rule != SSMAP_RULE_DIRECT ? gt[fbase + pix] : 0;
+        const float unc_v = unc ? unc[fbase + pix] : 0.0f;
+        const float maxp_v = maxp ? maxp[fbase + pix] : 0.0f;
+        float views = 0.0f, hits = 0.0f;
+        int bg = 0;
+        if (hv) {
+            views = mp.views[cell];
+            hits = mp.hits[cell];
+            bg = (int)mp.background_map[cell];
+        }
+        // height map (mapper.py:338-341)
+        const float h = fmaxf(h_old, (float)(unorder_f64(hk) - pb.agent[1]));
+        mp.height_map[cell] = h;
 
         if (v.rule == SSMAP_RULE_DIRECT) {
             id = occupancy_override(id, h, v.use_height, v.n_schema);
@@ -82,11 +98,11 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
             paint(mp, v.palette, cell, id);
             continue;
         }
-        mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
+        mp.gt_map[cell] = (uint32_t)gtv;
 
         if (v.rule == SSMAP_RULE_ARGMAX) {
-            if (unc) mp.unc_map[cell] = unc[fbase + pix];
-            if (v.prm.use_filter && id == goal && (1.0f - unc[fbase + pix]) < v.prm.filter_goal_prob) id = 0;
+            if (unc) mp.unc_map[cell] = unc_v;
+            if (v.prm.use_filter && id == goal && (1.0f - unc_v) < v.prm.filter_goal_prob) id = 0;
             id = occupancy_override(id, h, v.use_height, v.n_schema);
             mp.semantic_map[cell] = (uint32_t)id;
             paint(mp, v.palette, cell, id);
@@ -94,10 +110,10 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
         }
         if (hv) {
             const bool weighted = v.rule == SSMAP_RULE_PROB_HV;
-            if (weighted) mp.unc_map[cell] = unc[fbase + pix];
-            else if (v.prm.use_filter && id == goal && maxp[fbase + pix] < v.prm.filter_goal_prob) id = 0;
+            if (weighted) mp.unc_map[cell] = unc_v;
+            else if (v.prm.use_filter && id == goal && maxp_v < v.prm.filter_goal_prob) id = 0;
             id = occupancy_override(id, h, v.use_height, v.n_schema);
-            if (id != goal) mp.background_map[cell] = (uint32_t)id;
+            if (id != goal) { mp.background_map[cell] = (uint32_t)id; bg = id; }
 
             bool gated = true;
             if (v.prm.hv_limit_obj_view_dist > 0.0) {
@@ -109,18 +125,25 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
                 const double dz = ((double)row * v.p2m + mp.lower[2]) - pb.agent[2];
                 gated = sqrt(dx * dx + dz * dz) < v.prm.hv_limit_obj_view_dist;
             }
-            const float add = weighted ? maxp[fbase + pix] : 1.0f;
-            float views = mp.views[cell], hits = mp.hits[cell];
+            const float add = weighted ? maxp_v : 1.0f;
             if (!weighted || gated) { views += add; mp.views[cell] = views; }
             if (gated && raw == goal) { hits += add; mp.hits[cell] = hits; }
             const bool show = gated && hits > 0.0f && views != INFINITY;
-            const int shown = show ? goal : (int)mp.background_map[cell];
+            const int shown = show ? goal : bg;
             mp.semantic_map[cell] = (uint32_t)shown;
             paint(mp, v.palette, cell, shown);
-            if (show) {
+            // one counter bump per wave: every shown cell bumping the env's counter itself would
+            // serialise thousands of same-address atomics
+            const unsigned long long shown_lanes = __ballot(show);
+            if (shown_lanes) {
                 const int cur = v.cur_overlay;
-                const unsigned pos = atomicAdd(&v.overlay_count[cur][e], 1u);
-                v.overlay[cur][(int64_t)e * v.N + pos] = cell;
+                const int lane = threadIdx.x & 63;
+                const int leader = __ffsll((long long)shown_lanes) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&v.overlay_count[cur][e], (unsigned)__popcll(shown_lanes));
+                base = __shfl(base, leader);
+                if (show)
+                    v.overlay[cur][(int64_t)e * v.N + base + (unsigned)__popcll(shown_lanes & ((1ull << lane) - 1ull))] = cell;
             }
             continue;
         }

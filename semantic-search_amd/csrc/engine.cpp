@@ -239,8 +239,6 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.envs = eng->d_envs; v.poses = eng->d_poses; v.hdr = eng->d_hdr;
     v.lut = eng->d_lut; v.pool_ids = eng->d_pool_ids; v.pool_count = eng->d_pool_count;
     v.cur_overlay = 0;
-    // enough winner-table workgroups to cover the chip even for few envs
-    v.min_parts = c.n_envs <= 32 ? 16 : (c.n_envs <= 64 ? 8 : (c.n_envs <= 128 ? 4 : 2));
     *out = eng;
     return SSMAP_OK;
 }

@@ -1,5 +1,6 @@
 // Stages 2 and 3 of the fusion path for gfx950:
-//   k_geometry    depth -> world point -> map cell + height, one pass over the depth image
+//   k_geometry    depth -> world point -> map cell + height, one pass over the depth image;
+//                 per-block partials of the cell box and per-block pixel counts per winner table
 //                 (mapper.py:279-283 sentinels, :18-32 pointcloud, :305-311 rotate/translate,
 //                  :851-863 world2map, :319-329 masks)
 //   k_winners     tallest point per cell, ties -> lowest pixel index (mapper.py:331), then
@@ -54,6 +55,14 @@ __device__ inline double floor_div_known(double d, double p, double rp) {
 }
 
 // One thread = 4 horizontally adjacent pixels (W % 4 == 0 is checked on the host).
+// Table of a cell in the winner selection (see the binning section below): independent of the
+// frame's cell box, so the geometry kernel can already count its pixels per table.
+constexpr int kGeomBinParts = kMaxParts;
+__device__ inline int geom_cell_table(uint32_t id) {
+    const int row_b = (int)((id >> kCoordBits) & kCoordMask), col_b = (int)(id & kCoordMask);
+    return ((col_b >> 3) + row_b * 3) & (kGeomBinParts - 1);
+}
+
 // PACKED: the poses arrive as a kernel argument (batches of at most kPosePack envs: no
 // host-to-device copy in front of the step) and block 0 of every env stores its pose for the
 // later kernels; otherwise the poses are already in v.poses.
@@ -72,6 +81,9 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
     unsigned min_inv = kNoPixel;
     unsigned err = 0;
+    __shared__ unsigned int s_tab[kGeomBinParts];   // live pixels of this block per winner table
+    if (threadIdx.x < kGeomBinParts) s_tab[threadIdx.x] = 0;
+    __syncthreads();
 
     if (i0 < v.N) {
         const int r = i0 / v.W;
@@ -119,6 +131,7 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
                 err |= SSMAP_ENV_INDEX_ERROR;   // index below -dim: numpy raises IndexError
             }
             if (!ok) min_inv = min(min_inv, (unsigned)(i0 + k));
+            if (id != kDeadCell) atomicAdd(&s_tab[geom_cell_table(id)], 1u);
             ids[k] = id;
             hk[k] = key;
         }
@@ -149,145 +162,127 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             min_inv = min(min_inv, (unsigned)s_red[w][4]);
             err |= (unsigned)s_red[w][5];
         }
-        // per-block partial; k_frame_header folds them (hundreds of blocks hammering one header
+        // per-block partial; k_header_scan folds them (hundreds of blocks hammering one header
         // line with atomics serialise at the memory side)
         int *part = v.geo_part + ((int64_t)e * gridDim.x + blockIdx.x) * 8;
         *reinterpret_cast<int4 *>(part) = make_int4(rmin, rmax, cmin, cmax);
         *reinterpret_cast<int4 *>(part + 4) = make_int4((int)min_inv, (int)err, 0, 0);
     }
+    if (threadIdx.x < kGeomBinParts)   // layout [table][block]; the barrier above covers the LDS adds
+        v.bin_cnt[((int64_t)e * kGeomBinParts + threadIdx.x) * gridDim.x + blockIdx.x] = s_tab[threadIdx.x];
 }
 
-// One block per env: folds the geometry blocks' partials into the frame header and resets the
-// per-step counters.  (Folding inside every k_bin_count block instead was measured slower.)
-__global__ __launch_bounds__(256) void k_frame_header(View v, int nblk) {
-    __shared__ int s_red[4][6];
-    const int e = blockIdx.x;
-    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
-    unsigned min_inv = kNoPixel, err = 0;
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
-        const int *part = v.geo_part + ((int64_t)e * nblk + b) * 8;
-        const int4 a = *reinterpret_cast<const int4 *>(part);
-        const int4 c = *reinterpret_cast<const int4 *>(part + 4);
-        rmin = min(rmin, a.x); rmax = max(rmax, a.y); cmin = min(cmin, a.z); cmax = max(cmax, a.w);
-        min_inv = min(min_inv, (unsigned)c.x);
-        err |= (unsigned)c.y;
-    }
-    rmin = wave_min(rmin); rmax = wave_max(rmax);
-    cmin = wave_min(cmin); cmax = wave_max(cmax);
-    min_inv = wave_minu(min_inv);
-    for (int o = 32; o > 0; o >>= 1) err |= (unsigned)__shfl_xor((int)err, o);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
-        s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
-            rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
-            cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
-            min_inv = min(min_inv, (unsigned)s_red[w][4]);
-            err |= (unsigned)s_red[w][5];
-        }
-        FrameHeader h;
-        h.rmin = rmin; h.rmax = rmax; h.cmin = cmin; h.cmax = cmax;
-        h.wrmin = h.wcmin = 0x7FFFFFFF;
-        h.wrmax = h.wcmax = (int32_t)0x80000000;
-        h.min_invalid_pixel = min_inv;
-        h.n_winners = 0;
-        h.status = err;
-        h.found = 0;
-        h.any_goal = 0;
-        h.n_overlay = 0;
-        h.n_neg = 0;
-        h.pad = 0;
-        v.hdr[e] = h;
-        v.overlay_count[v.cur_overlay][e] = 0;
-    }
-}
+// Binning: the live pixels of a frame are sorted by winner table into contiguous arrays of
+// 12-byte records {height image, slot << 19 | pixel} so that a winner-table block reads only its
+// own records instead of every pixel of the frame.  The geometry kernel already counts its
+// pixels per table, so two small kernels remain: prefix sums (with the frame header) and scatter.
+// Record order inside a table is arbitrary (the table reductions are order independent).
+//
+// Deal of cells to tables: runs of 8 cells of one map row ("chunks", numbered cc along the row
+// in absolute biased coordinates) go to table (cc + 3 row) mod 16.  The table of a cell thus does
+// not depend on the frame's cell box, which is why the geometry kernel can count before the box
+// is known; the skew by 3 per row spreads a wall seen edge-on over all tables.  Inside a table a
+// cell's slot is dense over the box padded to a multiple of 16 chunks per row:
+//   slot = ((row - rmin) * per_row + (cc - cc0) / 16) * 8 + col % 8,   per_row = ceil(ncc / 16).
+// A box whose padded cells exceed 16 tables of kSlots (about 131 thousand cells: far beyond what
+// a 5 m depth range reaches at 3 cm) is not binned; the winner kernel scans all cell ids then.
+constexpr int kBinParts = kMaxParts;          // 16 tables per frame
+constexpr int kBinShift = 4;
+constexpr int kChunkShift = 3, kChunkMask = (1 << kChunkShift) - 1;
+constexpr int kRowSkew = 3;
+static_assert((1 << kBinShift) == kBinParts, "kBinShift must be log2 of kBinParts");
 
-// Binning: the live pixels of a frame are sorted by winner table (cell number >> 13 inside the
-// frame's cell box) into one contiguous array of 16-byte records
-//   {pixel << 1 | not-updatable, slot in table, height image lo, hi}
-// so that a winner-table block reads only its own records instead of every pixel of the frame.
-// Three small kernels: per-block histogram, prefix sums, scatter.  Record order inside a table
-// is arbitrary (the table reductions are order independent).
-// Cells of the frame's box are numbered row-major (L); runs of kInterleave consecutive cells are
-// dealt round-robin to the nparts tables so that every table sees a similar share of pixels
-// whatever the view direction:  chunk = L / 32, table = chunk % nparts,
-// slot = (chunk / nparts) * 32 + L % 32.
-constexpr int kInterleaveShift = 5, kInterleave = 1 << kInterleaveShift;
 struct BinFrame {
     bool on;
-    int bw, rmin_b, cmin_b, nparts;
+    int rmin_b, cc0, per_row;
 };
-__device__ inline void split_cell(int L, int nparts, int &part, int &slot) {
-    const int chunk = L >> kInterleaveShift;
-    const int q = chunk / nparts;
-    part = chunk - q * nparts;
-    slot = (q << kInterleaveShift) | (L & (kInterleave - 1));
-}
-__device__ inline long long join_cell(int part, int slot, int nparts) {
-    const long long chunk = (long long)(slot >> kInterleaveShift) * nparts + part;
-    return (chunk << kInterleaveShift) | (slot & (kInterleave - 1));
-}
-__device__ inline BinFrame bin_frame(const FrameHeader *hdr, int min_parts) {
+static_assert(kChunkShift == 3 && kRowSkew == 3, "geom_cell_table spells these constants out");
+__device__ inline int cell_table(uint32_t id) { return geom_cell_table(id); }
+__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
     BinFrame f;
     f.on = false;
     const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
     if (rmin > rmax) return f;
-    f.bw = cmax - cmin + 1;
-    const long long ncell = (long long)f.bw * (long long)(rmax - rmin + 1);
-    const long long np = (ncell + kSlots - 1) >> kSlotShift;
-    if (np > kMaxParts) return f;
-    // at least min_parts tables per frame so that a small cell box still spreads its pixels
-    // over enough workgroups
-    f.nparts = max((int)np, min_parts);
     f.rmin_b = rmin + kCoordBias;
-    f.cmin_b = cmin + kCoordBias;
-    f.on = true;
+    f.cc0 = (cmin + kCoordBias) >> kChunkShift;
+    const int cc1 = (cmax + kCoordBias) >> kChunkShift;
+    f.per_row = (cc1 - f.cc0 + kBinParts) >> kBinShift;
+    f.on = ((long long)(rmax - rmin + 1) * f.per_row << kChunkShift) <= kSlots;
     return f;
 }
-__device__ inline int bin_cell(const BinFrame &f, uint32_t id) {
-    const int rr = (int)((id >> kCoordBits) & kCoordMask) - f.rmin_b;
-    const int cc = (int)(id & kCoordMask) - f.cmin_b;
-    return rr * f.bw + cc;
+__device__ inline int cell_slot(const BinFrame &f, uint32_t id) {
+    const int row_b = (int)((id >> kCoordBits) & kCoordMask), col_b = (int)(id & kCoordMask);
+    const int j = (col_b >> kChunkShift) - f.cc0;
+    return (((row_b - f.rmin_b) * f.per_row + (j >> kBinShift)) << kChunkShift) | (col_b & kChunkMask);
+}
+// inverse of (cell_table, cell_slot): unbiased cell of a slot of a table
+__device__ inline void slot_cell(const BinFrame &f, int table, int slot, int &row, int &col) {
+    const int kc = slot >> kChunkShift;
+    const int row_rel = kc / f.per_row, kk = kc - row_rel * f.per_row;
+    const int row_b = f.rmin_b + row_rel;
+    const int j = ((table - f.cc0 - row_b * kRowSkew) & (kBinParts - 1)) + (kk << kBinShift);
+    row = row_b - kCoordBias;
+    col = (((f.cc0 + j) << kChunkShift) | (slot & kChunkMask)) - kCoordBias;
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(View v) {
-    __shared__ unsigned int cnt[kMaxParts];
-    const int e = blockIdx.y;
-    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
-    if (!f.on) return;
-    if (threadIdx.x < kMaxParts) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 < v.N) {
-        const uint4 id4 = *reinterpret_cast<const uint4 *>(v.cellid + (int64_t)e * v.N + i0);
-        const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ids[k] != kDeadCell) {
-                int part, slot;
-                split_cell(bin_cell(f, ids[k]), f.nparts, part, slot);
-                atomicAdd(&cnt[part], 1u);
-            }
-    }
-    __syncthreads();
-    if (threadIdx.x < f.nparts)   // layout [table][block]
-        v.bin_cnt[((int64_t)e * kMaxParts + threadIdx.x) * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// One block per frame: bin_cnt[p][b] (count) -> first record index of block b's pixels for
-// table p; part_start[p] = first record of table p.
-__global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
-    __shared__ unsigned int total[kMaxParts + 1];
+// One block per frame: folds the geometry blocks' partials into the frame header, resets the
+// per-step counters, and turns the per-block table counts bin_cnt[p][b] into the first record
+// index of block b's pixels for table p; part_start[p] = first record of table p.
+__global__ __launch_bounds__(1024) void k_header_scan(View v, int nbin) {
+    __shared__ unsigned int total[kBinParts + 1];
+    __shared__ int s_red[16][6];
+    __shared__ FrameHeader s_hdr;
     const int e = blockIdx.x;
-    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
-    if (!f.on) return;
-    unsigned int *cnt = v.bin_cnt + (int64_t)e * kMaxParts * nbin;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int p = wave; p < f.nparts; p += 16) {
+    {
+        int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
+        unsigned min_inv = kNoPixel, err = 0;
+        for (int b = threadIdx.x; b < nbin; b += blockDim.x) {
+            const int *part = v.geo_part + ((int64_t)e * nbin + b) * 8;
+            const int4 a = *reinterpret_cast<const int4 *>(part);
+            const int4 c = *reinterpret_cast<const int4 *>(part + 4);
+            rmin = min(rmin, a.x); rmax = max(rmax, a.y); cmin = min(cmin, a.z); cmax = max(cmax, a.w);
+            min_inv = min(min_inv, (unsigned)c.x);
+            err |= (unsigned)c.y;
+        }
+        rmin = wave_min(rmin); rmax = wave_max(rmax);
+        cmin = wave_min(cmin); cmax = wave_max(cmax);
+        min_inv = wave_minu(min_inv);
+        for (int o = 32; o > 0; o >>= 1) err |= (unsigned)__shfl_xor((int)err, o);
+        if (lane == 0) {
+            s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
+            s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 16; ++w) {
+                rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
+                cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
+                min_inv = min(min_inv, (unsigned)s_red[w][4]);
+                err |= (unsigned)s_red[w][5];
+            }
+            FrameHeader h;
+            h.rmin = rmin; h.rmax = rmax; h.cmin = cmin; h.cmax = cmax;
+            h.wrmin = h.wcmin = 0x7FFFFFFF;
+            h.wrmax = h.wcmax = (int32_t)0x80000000;
+            h.min_invalid_pixel = min_inv;
+            h.n_winners = 0;
+            h.status = err;
+            h.found = 0;
+            h.any_goal = 0;
+            h.n_overlay = 0;
+            h.n_neg = 0;
+            h.pad = 0;
+            s_hdr = h;
+            v.hdr[e] = h;
+            v.overlay_count[v.cur_overlay][e] = 0;
+        }
+        __syncthreads();
+    }
+    if (!bin_frame(&s_hdr).on) return;
+    unsigned int *cnt = v.bin_cnt + (int64_t)e * kBinParts * nbin;
+    {
+        const int p = wave;       // 16 waves, 16 tables
         unsigned sum = 0;
         for (int b = lane; b < nbin; b += 64) sum += cnt[p * nbin + b];
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -296,12 +291,13 @@ __global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned run = 0;
-        for (int p = 0; p < f.nparts; ++p) { const unsigned c = total[p]; total[p] = run; run += c; }
-        for (int p = f.nparts; p <= kMaxParts; ++p) total[p] = run;
+        for (int p = 0; p < kBinParts; ++p) { const unsigned c = total[p]; total[p] = run; run += c; }
+        total[kBinParts] = run;
     }
     __syncthreads();
-    if (threadIdx.x <= kMaxParts) v.part_start[e * (kMaxParts + 1) + threadIdx.x] = total[threadIdx.x];
-    for (int p = wave; p < f.nparts; p += 16) {
+    if (threadIdx.x <= kBinParts) v.part_start[e * (kBinParts + 1) + threadIdx.x] = total[threadIdx.x];
+    {
+        const int p = wave;
         unsigned run = total[p];
         for (int b0 = 0; b0 < nbin; b0 += 64) {
             const int b = b0 + lane;
@@ -319,16 +315,15 @@ __global__ __launch_bounds__(1024) void k_bin_scan(View v, int nbin) {
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
-    __shared__ unsigned int cnt[kMaxParts];
-    __shared__ unsigned int base[kMaxParts];
+    __shared__ unsigned int cnt[kBinParts];
+    __shared__ unsigned int base[kBinParts];
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
-    const BinFrame f = bin_frame(v.hdr + e, v.min_parts);
+    const BinFrame f = bin_frame(v.hdr + e);
     if (!f.on) return;
-    if (threadIdx.x < kMaxParts) {
+    if (threadIdx.x < kBinParts) {
         cnt[threadIdx.x] = 0;
-        base[threadIdx.x] = threadIdx.x < f.nparts
-            ? v.bin_cnt[((int64_t)e * kMaxParts + threadIdx.x) * gridDim.x + blockIdx.x] : 0u;
+        base[threadIdx.x] = v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x];
     }
     __syncthreads();
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -341,8 +336,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(View v) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (ids[k] == kDeadCell) continue;
-        int part, slot;
-        split_cell(bin_cell(f, ids[k]), f.nparts, part, slot);
+        const int part = cell_table(ids[k]), slot = cell_slot(f, ids[k]);
         const unsigned pos = base[part] + atomicAdd(&cnt[part], 1u);
         v.rec_h[fbase + pos] = hk[k];
         if (PACKED) {
@@ -426,7 +420,7 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
     const int nfull = (int)((ncell + kSlots - 1) >> kSlotShift);
     const int rmin_b = rmin + kCoordBias, cmin_b = cmin + kCoordBias;
-    const int nparts = RUNS ? max(nfull, v.min_parts) : nfull;
+    const int nparts = RUNS ? kBinParts : nfull;
 
     // the cell all invalid-depth pixels fall into (they sit at the camera position,
     // mapper.py:28-31) and their common height
@@ -447,8 +441,14 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 
     int inv_part = -1, inv_slot = 0;
     if (inv_L >= 0) {
-        if (RUNS) split_cell((int)inv_L, nparts, inv_part, inv_slot);
-        else { inv_part = (int)(inv_L >> kSlotShift); inv_slot = (int)(inv_L & (kSlots - 1)); }
+        if (RUNS) {
+            const uint32_t id = ((uint32_t)((int)(inv_L / bw) + rmin_b) << kCoordBits) | (uint32_t)((int)(inv_L % bw) + cmin_b);
+            inv_part = cell_table(id);
+            inv_slot = cell_slot(bin_frame(hdr), id);
+        } else {
+            inv_part = (int)(inv_L >> kSlotShift);
+            inv_slot = (int)(inv_L & (kSlots - 1));
+        }
     }
     const uint4 *ids4 = reinterpret_cast<const uint4 *>(v.cellid + fbase);
     const unsigned long long *hk = v.horder + fbase;
@@ -580,10 +580,16 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
             const int s = it * kWinnerThreads + threadIdx.x;
             if (!((balls[it] >> lane) & 1ull)) continue;
             const unsigned w = table_i[s];
-            // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
-            const unsigned L = RUNS ? (unsigned)join_cell(p, s, nparts) : ((unsigned)p << kSlotShift) + (unsigned)s;
-            const unsigned lrow = L / (unsigned)bw;
-            const int row = (int)lrow + rmin, col = (int)(L - lrow * (unsigned)bw) + cmin;
+            int row, col;
+            if (RUNS) {
+                slot_cell(bin_frame(hdr), p, s, row, col);   // recomputed here: keeps it out of the registers above
+            } else {
+                // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
+                const unsigned L = ((unsigned)p << kSlotShift) + (unsigned)s;
+                const unsigned lrow = L / (unsigned)bw;
+                row = (int)lrow + rmin;
+                col = (int)(L - lrow * (unsigned)bw) + cmin;
+            }
             lrmin = min(lrmin, row); lrmax = max(lrmax, row);
             lcmin = min(lcmin, col); lcmax = max(lcmax, col);
             // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
@@ -628,14 +634,13 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     }
 }
 
-// Frames whose cell box needs at most kMaxParts tables are binned (k_bin_*) and read as
-// contiguous record ranges; larger boxes fall back to scanning every cell id once per table.
+// Frames whose padded cell box fits the 16 tables are binned (k_header_scan, k_bin_scatter) and
+// read as contiguous record ranges; larger boxes fall back to scanning every cell id once per table.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
     __shared__ WinnerShared sh;
     const FrameHeader *hdr = v.hdr + blockIdx.y;
-    const long long ncell = (long long)(hdr->cmax - hdr->cmin + 1) * (long long)(hdr->rmax - hdr->rmin + 1);
     if (hdr->rmin > hdr->rmax) return;
-    if (((ncell + kSlots - 1) >> kSlotShift) > kMaxParts) winners_body<false, false>(v, write_target, write_list, sh);
+    if (!bin_frame(hdr).on) winners_body<false, false>(v, write_target, write_list, sh);
     else if (v.rec_packed) winners_body<true, true>(v, write_target, write_list, sh);
     else winners_body<true, false>(v, write_target, write_list, sh);
 }
@@ -689,7 +694,6 @@ void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host
     } else {
         hipLaunchKernelGGL(k_geometry<false>, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0, pack);
     }
-    hipLaunchKernelGGL(k_frame_header, dim3(v.E), dim3(256), 0, s, v, (int)grid.x);
 }
 
 void launch_winners(const View &v, hipStream_t s) {
@@ -697,8 +701,7 @@ void launch_winners(const View &v, hipStream_t s) {
     dim3 grid(kWinnerPartsPerEnv, v.E);
     const int nbin = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     dim3 grid_bin(nbin, v.E);
-    hipLaunchKernelGGL(k_bin_count, grid_bin, dim3(256), 0, s, v);
-    hipLaunchKernelGGL(k_bin_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
+    hipLaunchKernelGGL(k_header_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
     if (v.rec_packed) hipLaunchKernelGGL(k_bin_scatter<true>, grid_bin, dim3(256), 0, s, v);
     else hipLaunchKernelGGL(k_bin_scatter<false>, grid_bin, dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);

@@ -23,7 +23,7 @@ constexpr int kSlotShift = 13;
 constexpr int kPackPixBits = 32 - kSlotShift;   // slot and pixel share one record word when N <= 2^19
 constexpr int kGeomPixPerBlock = 1024;        // geometry kernel: 256 threads x 4 pixels
 constexpr int kWinnerThreads = 1024;
-constexpr int kMaxParts = 64;                // binned path: tables per frame (cell box <= 512 Ki cells)
+constexpr int kMaxParts = 16;                // winner tables per frame on the binned path
 constexpr int kWinnerPartsPerEnv = 16;        // blocks launched per env for the winner kernel
 
 // Per-env, per-step geometry constants: the host derives them from the two pose vectors
@@ -100,7 +100,6 @@ struct View {
     uint8_t *local_eroded;     // goal_decay: same shape
     int32_t *overlay[2];       // hv: [E][N] cells showing the goal overlay (prev / current)
     uint32_t *overlay_count[2];// [E]
-    int32_t min_parts;         // winner tables per frame at least (<= kWinnerPartsPerEnv)
     int32_t cur_overlay;       // which of the two lists is written this step
     int64_t local_stride;      // bytes per env in local_ids
     const int32_t *lut;        // [C] model class -> schema id

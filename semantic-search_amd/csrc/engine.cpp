@@ -541,7 +541,7 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     MARK(0);
     launch_geometry(v, *f, packed ? pb : nullptr, stream);
     MARK(1);
-    launch_winners(v, stream);
+    launch_winners(v, *f, stream);
     launch_resolve_wrapped(v, stream);
     MARK(2);
     if (prob_rule) {

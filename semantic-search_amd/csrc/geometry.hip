@@ -1,6 +1,6 @@
 // Stages 2 and 3 of the fusion path for gfx950:
-//   k_geometry    depth -> world point -> map cell + height, one pass over the depth image;
-//                 per-block partials of the cell box and per-block pixel counts per winner table
+//   k_geometry_count / k_geometry_scatter   depth -> world point -> map cell + height, run twice
+//                 over the depth image (count per winner table, then scatter into the tables)
 //                 (mapper.py:279-283 sentinels, :18-32 pointcloud, :305-311 rotate/translate,
 //                  :851-863 world2map, :319-329 masks)
 //   k_winners     tallest point per cell, ties -> lowest pixel index (mapper.py:331), then
@@ -63,12 +63,70 @@ __device__ inline int geom_cell_table(uint32_t id) {
     return ((col_b >> 3) + row_b * 3) & (kGeomBinParts - 1);
 }
 
+// What the path needs to know about one pixel.
+struct PixelGeom {
+    uint32_t id;                // biased cell | kUpdBit, or kDeadCell when it takes no part
+    unsigned long long key;     // order-preserving image of its height
+    bool in_box;                // cell inside [-dim, dim): counts for the frame's cell box
+    int row, col;
+    bool index_error;           // passes the filters but lies below -dim (numpy raises)
+    bool invalid;               // depth <= 0 after sentinel zeroing
+};
+
+// depth -> world point -> map cell and height (mapper.py:18-32, 305-311, 851-863, 319-329);
+// dk is the depth after sentinel zeroing, (u, yr) = (column, row - H/2).
+__device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
+                                           float dk, int u, double yr) {
+    PixelGeom g;
+    const int Hm = mp.map_h, Wm = mp.map_w;
+    const bool ok = dk > 0.0f;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (ok) {
+        z = (double)dk;
+        x = div_known(z * ((double)u - (double)v.W / 2.0), v.fx, v.inv_fx);
+        y = div_known(z * yr, v.fy, v.inv_fy);
+    }
+    const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
+    const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
+    const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
+    const double fr = floor_div_known(wz - mp.lower[2], v.p2m, v.inv_p2m);
+    const double fc = floor_div_known(wx - mp.lower[0], v.p2m, v.inv_p2m);
+    g.id = kDeadCell;
+    g.key = 0;
+    g.row = g.col = 0;
+    g.invalid = !ok;
+    // comparisons in double so that huge or non-finite coordinates never reach a cast
+    const bool below_upper = fr < (double)Hm && fc < (double)Wm;
+    const bool above_lower = fr >= -(double)Hm && fc >= -(double)Wm;
+    const bool pass = ok && (wy < pb.h_cut);
+    g.in_box = below_upper && above_lower && wy == wy;
+    g.index_error = !g.in_box && below_upper && !above_lower && pass;   // index below -dim: numpy raises IndexError
+    if (g.in_box) {
+        g.row = (int)fr;
+        g.col = (int)fc;
+        if (ok) {
+            g.id = ((uint32_t)(g.row + kCoordBias) << kCoordBits) | (uint32_t)(g.col + kCoordBias);
+            if (pass) g.id |= kUpdBit;
+            g.key = order_f64(wy);
+        }
+    }
+    return g;
+}
+
+// The geometry runs twice over the depth image instead of parking 12 bytes per pixel in HBM
+// between a counting and a scattering kernel:
+//   k_geometry_count    cells only: per-block pixel counts per winner table, per-block partials of
+//                       the cell box / lowest invalid pixel / error bits.  No per-pixel output.
+//   (k_header_scan      frame header, prefix sums)
+//   k_geometry_scatter  the same arithmetic again; zeroes the depth sentinels in place, clears the
+//                       owner flags and writes each live pixel's 12-byte record straight into its
+//                       table's range (or, for a frame too large to bin, cell ids and heights
+//                       per pixel for the scanning winner kernel).
 // PACKED: the poses arrive as a kernel argument (batches of at most kPosePack envs: no
 // host-to-device copy in front of the step) and block 0 of every env stores its pose for the
 // later kernels; otherwise the poses are already in v.poses.
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all,
-                                                  int write_target, PosePack pack) {
+__global__ __launch_bounds__(256) void k_geometry_count(View v, const float *__restrict__ depth_all, PosePack pack) {
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -76,7 +134,6 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     if (PACKED && blockIdx.x == 0 && threadIdx.x < sizeof(PoseBlock) / 8)
         reinterpret_cast<double *>(v.poses + e)[threadIdx.x] = reinterpret_cast<const double *>(&pb)[threadIdx.x];
     const ssmap_env_maps &mp = v.envs[e].maps;
-    const int Hm = mp.map_h, Wm = mp.map_w;
 
     int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
     unsigned min_inv = kNoPixel;
@@ -88,59 +145,21 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     if (i0 < v.N) {
         const int r = i0 / v.W;
         const int c0 = i0 - r * v.W;
-        float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
-        float d[4] = {d4.x, d4.y, d4.z, d4.w};
-        bool dirty = false;
-        uint32_t ids[4];
-        unsigned long long hk[4];
-        const double half_w = (double)v.W / 2.0, half_h = (double)v.H / 2.0;
-        const double yr = (double)r - half_h;
+        const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const double yr = (double)r - (double)v.H / 2.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float dk = d[k];
-            if (dk == v.depth_min || dk == v.depth_max) { dk = 0.0f; dirty = true; }
-            d[k] = dk;
-            const bool ok = dk > 0.0f;
-            double x = 0.0, y = 0.0, z = 0.0;
-            if (ok) {
-                z = (double)dk;
-                x = div_known(z * ((double)(c0 + k) - half_w), v.fx, v.inv_fx);
-                y = div_known(z * yr, v.fy, v.inv_fy);
+            const float dk = (d[k] == v.depth_min || d[k] == v.depth_max) ? 0.0f : d[k];   // mapper.py:279-283
+            const PixelGeom g = pixel_geometry(v, pb, mp, dk, c0 + k, yr);
+            if (g.in_box) {
+                rmin = min(rmin, g.row); rmax = max(rmax, g.row);
+                cmin = min(cmin, g.col); cmax = max(cmax, g.col);
             }
-            const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
-            const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
-            const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
-            const double fr = floor_div_known(wz - mp.lower[2], v.p2m, v.inv_p2m);
-            const double fc = floor_div_known(wx - mp.lower[0], v.p2m, v.inv_p2m);
-            uint32_t id = kDeadCell;
-            unsigned long long key = 0;
-            // comparisons in double so that huge or non-finite coordinates never reach a cast
-            const bool below_upper = fr < (double)Hm && fc < (double)Wm;
-            const bool above_lower = fr >= -(double)Hm && fc >= -(double)Wm;
-            const bool pass = ok && (wy < pb.h_cut);
-            if (below_upper && above_lower && wy == wy) {
-                const int row = (int)fr, col = (int)fc;
-                rmin = min(rmin, row); rmax = max(rmax, row);
-                cmin = min(cmin, col); cmax = max(cmax, col);
-                if (ok) {
-                    id = ((uint32_t)(row + kCoordBias) << kCoordBits) | (uint32_t)(col + kCoordBias);
-                    if (pass) id |= kUpdBit;
-                    key = order_f64(wy);
-                }
-            } else if (below_upper && !above_lower && pass) {
-                err |= SSMAP_ENV_INDEX_ERROR;   // index below -dim: numpy raises IndexError
-            }
-            if (!ok) min_inv = min(min_inv, (unsigned)(i0 + k));
-            if (id != kDeadCell) atomicAdd(&s_tab[geom_cell_table(id)], 1u);
-            ids[k] = id;
-            hk[k] = key;
+            if (g.index_error) err |= SSMAP_ENV_INDEX_ERROR;
+            if (g.invalid) min_inv = min(min_inv, (unsigned)(i0 + k));
+            if (g.id != kDeadCell) atomicAdd(&s_tab[geom_cell_table(g.id)], 1u);
         }
-        if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
-        *reinterpret_cast<uint4 *>(v.cellid + fbase + i0) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
-        unsigned long long *hp = v.horder + fbase + i0;
-        *reinterpret_cast<ulonglong2 *>(hp) = make_ulonglong2(hk[0], hk[1]);
-        *reinterpret_cast<ulonglong2 *>(hp + 2) = make_ulonglong2(hk[2], hk[3]);
-        if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
     }
 
     // block reduction of the bbox, the lowest invalid pixel and the error bits
@@ -314,25 +333,46 @@ __global__ __launch_bounds__(1024) void k_header_scan(View v, int nbin) {
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_bin_scatter(View v) {
+__global__ __launch_bounds__(256) void k_geometry_scatter(View v, float *__restrict__ depth_all, int write_target) {
     __shared__ unsigned int cnt[kBinParts];
     __shared__ unsigned int base[kBinParts];
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
+    const PoseBlock &pb = v.poses[e];
+    const ssmap_env_maps &mp = v.envs[e].maps;
     const BinFrame f = bin_frame(v.hdr + e);
-    if (!f.on) return;
     if (threadIdx.x < kBinParts) {
         cnt[threadIdx.x] = 0;
-        base[threadIdx.x] = v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x];
+        base[threadIdx.x] = f.on ? v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x] : 0u;
     }
     __syncthreads();
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= v.N) return;
-    const uint4 id4 = *reinterpret_cast<const uint4 *>(v.cellid + fbase + i0);
-    const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
-    const ulonglong2 h01 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0);
-    const ulonglong2 h23 = *reinterpret_cast<const ulonglong2 *>(v.horder + fbase + i0 + 2);
-    const unsigned long long hk[4] = {h01.x, h01.y, h23.x, h23.y};
+    const int r = i0 / v.W;
+    const int c0 = i0 - r * v.W;
+    const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
+    float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    const double yr = (double)r - (double)v.H / 2.0;
+    bool dirty = false;
+    uint32_t ids[4];
+    unsigned long long hk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (d[k] == v.depth_min || d[k] == v.depth_max) { d[k] = 0.0f; dirty = true; }
+        const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
+        ids[k] = g.id;
+        hk[k] = g.key;
+    }
+    if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
+    if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+    if (!f.on) {
+        // not binned: the scanning winner kernel reads cell id and height per pixel
+        *reinterpret_cast<uint4 *>(v.cellid + fbase + i0) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+        unsigned long long *hp = v.horder + fbase + i0;
+        *reinterpret_cast<ulonglong2 *>(hp) = make_ulonglong2(hk[0], hk[1]);
+        *reinterpret_cast<ulonglong2 *>(hp + 2) = make_ulonglong2(hk[2], hk[3]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (ids[k] == kDeadCell) continue;
@@ -685,25 +725,23 @@ void launch_resolve_wrapped(const View &v, hipStream_t s) {
 
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
-    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
     PosePack pack;
     if (host_poses) {   // at most kPosePack envs
         memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);
-        hipLaunchKernelGGL(k_geometry<true>, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0, pack);
+        hipLaunchKernelGGL(k_geometry_count<true>, grid, dim3(256), 0, s, v, f.depth, pack);
     } else {
-        hipLaunchKernelGGL(k_geometry<false>, grid, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0, pack);
+        hipLaunchKernelGGL(k_geometry_count<false>, grid, dim3(256), 0, s, v, f.depth, pack);
     }
+    hipLaunchKernelGGL(k_header_scan, dim3(v.E), dim3(1024), 0, s, v, (int)grid.x);
 }
 
-void launch_winners(const View &v, hipStream_t s) {
+void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    const int nbin = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
-    dim3 grid_bin(nbin, v.E);
-    hipLaunchKernelGGL(k_header_scan, dim3(v.E), dim3(1024), 0, s, v, nbin);
-    if (v.rec_packed) hipLaunchKernelGGL(k_bin_scatter<true>, grid_bin, dim3(256), 0, s, v);
-    else hipLaunchKernelGGL(k_bin_scatter<false>, grid_bin, dim3(256), 0, s, v);
+    dim3 grid_geo((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
+    if (v.rec_packed) hipLaunchKernelGGL(k_geometry_scatter<true>, grid_geo, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
+    else hipLaunchKernelGGL(k_geometry_scatter<false>, grid_geo, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
     hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
 }
 

@@ -30,8 +30,8 @@ __device__ inline void paint(const ssmap_env_maps &mp, const uint8_t *palette, i
 }
 
 __device__ inline float raise_height(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
-                                     int64_t fbase, int pix, int cell) {
-    const double h = unorder_f64(v.horder[fbase + pix]);
+                                     int64_t fbase, unsigned slot, int cell) {
+    const double h = unorder_f64(v.wheight[fbase + slot]);
     const float hn = fmaxf(mp.height_map[cell], (float)(h - pb.agent[1]));
     mp.height_map[cell] = hn;
     return hn;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
         // every gather of this cell is issued before the first store (the stores could alias the
         // loads as far as the compiler knows, and would otherwise chain the round trips)
         const float h_old = mp.height_map[cell];
-        const unsigned long long hk = v.horder[fbase + pix];
+        const unsigned long long hk = v.wheight[fbase + i];   // height image of this list slot's pixel
         int id = semantic[fbase + pix];
         const int raw = id;
         const int gtv = v.rule != SSMAP_RULE_DIRECT ? gt[fbase + pix] : 0;
@@ -187,7 +187,7 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
         if (!lost) {
-            raise_height(v, mp, pb, fbase, pix, cell);
+            raise_height(v, mp, pb, fbase, i, cell);
             mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
         }
         int id = semantic[fbase + pix];

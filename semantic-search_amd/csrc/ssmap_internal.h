@@ -162,7 +162,7 @@ struct EgoTables {
 
 // launchers (defined in the .hip files)
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s);
-void launch_winners(const View &v, hipStream_t s);
+void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_resolve_wrapped(const View &v, hipStream_t s);
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);

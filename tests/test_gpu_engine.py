@@ -156,6 +156,44 @@ def test_frame_above_packed_record_limit():
     eng.close()
 
 
+def test_far_depths_take_the_unbinned_winner_path():
+    """Depths up to 30 m on a 960 x 960 map: the frame's cell box is far larger than the winner
+    tables hold, so the engine writes cell ids per pixel and every table block scans them."""
+    import semantic_search_amd as ssa
+    h, w, c = 120, 160, 8
+    lut = scenes.small_lut(c)
+    bounds = np.array([0.0, 0.0, 0.0, 28.79, 3.0, 28.79])
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 40.0), probablistic_mapping=True,
+              prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(bounds, 0.03), **kw)
+    eng.set_schema(lut)
+    ref.reset(bounds)
+    maps = eng.reset_env(0, bounds)
+    rng, prng = np.random.default_rng(21), np.random.default_rng(22)
+    for i in range(2):
+        frame = scenes.uniform_frame(rng, h, w, c, 1.0, depth_range=(0.5, 40.0), lut=lut)
+        frame["depth"] = np.where(frame["depth"] == np.float32(0.5), frame["depth"],
+                                  rng.uniform(1.0, 30.0, (h, w)).astype(np.float32))
+        agent, cam = scenes.make_pose(14.0, 0.0, 14.0, prng.uniform(0, 2 * np.pi))
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs["depth"] = frame["depth"].copy()
+        ref.update(obs)
+        eng.step(_to_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 probs=_to_dev(frame["semantic_prob"][None], np.float32),
+                 semantic_gt=_to_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        assert status[0] == 0
+        pix, _ = eng.update_list(0, int(n_upd[0]))
+        assert np.array_equal(np.sort(pix), np.sort(ref.last_update_pixels)), f"frame {i}: update set"
+    rows = np.nonzero(np.isfinite(ref.height_map).any(axis=1))[0]
+    assert rows.max() - rows.min() > 500, "the scene must spread over more rows than the tables can bin"
+    _close(maps["avg_prob_seg_map"].cpu().numpy(), ref.avg_prob_seg_map, "avg_prob_seg_map")
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+    eng.close()
+
+
 def test_segformer_style_150_classes_w2():
     eng, maps, ref, log = _run_pair("height_map_w2_avg_prob", 150, 2.5, 2, (120, 160), True,
                                     attrs=dict(entropy_threshold=0.482), bounds=BOUNDS_480)

@@ -125,8 +125,8 @@ def cpu_baseline(workload, n_frames, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="log_odds_c40", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -29,32 +29,33 @@ __device__ inline unsigned wave_minu(unsigned x) {
 // Correctly rounded a / b for a divisor known in advance (rb = RN(1/b) from the host).  Two
 // fused steps give a candidate q; the exact residual r = a - b*q then PROVES that q is the
 // nearest double (|r| strictly below half an ulp of q times |b|, q not a power of two), in
-// which case q equals the IEEE quotient; any other case runs the hardware division.
-__device__ inline double div_known(double a, double b, double rb) {
+// which case q equals the IEEE quotient.  `sure` is cleared when the proof fails; the caller
+// then redoes the whole pixel with hardware divisions (one rare branch per pixel instead of one
+// per division).
+__device__ inline double div_known(double a, double b, double rb, bool &sure) {
     const double q0 = a * rb;
-    if (a == 0.0) return q0;   // signed zero, as a / b gives
     const double q = __builtin_fma(__builtin_fma(-b, q0, a), rb, q0);
     const double r = __builtin_fma(-b, q, a);
     const unsigned long long bits = (unsigned long long)__builtin_bit_cast(long long, q);
     const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
     const bool plain = ex > 60u && ex < 0x7FEu && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
     const double half_ulp = __builtin_bit_cast(double, (long long)((unsigned long long)(ex - 53u) << 52));
-    if (plain && fabs(r) < half_ulp * fabs(b) * 0.999) return q;
-    return a / b;
+    // a == 0 gives the signed zero a / b gives
+    sure &= (a == 0.0) | (plain & (fabs(r) < half_ulp * fabs(b) * 0.999));
+    return a == 0.0 ? q0 : q;
 }
 
 // floor(RN(d / p)) for a divisor known in advance: d * RN(1/p) is within 3.4e-16 relative of
 // the rounded quotient, so away from the integers (guard band 1e-7, |q| < 2^24) both floors
-// agree; inside the band the quotient is recomputed with the hardware division.
-__device__ inline double floor_div_known(double d, double p, double rp) {
+// agree; inside the band `sure` is cleared.
+__device__ inline double floor_div_known(double d, double rp, bool &sure) {
     const double qf = d * rp;
     const double fl = floor(qf);
     const double frac = qf - fl;
-    if (fabs(qf) < 16777216.0 && frac > 1.0e-7 && frac < 1.0 - 1.0e-7) return fl;
-    return floor(d / p);
+    sure &= (fabs(qf) < 16777216.0) & (frac > 1.0e-7) & (frac < 1.0 - 1.0e-7);
+    return fl;
 }
 
-// One thread = 4 horizontally adjacent pixels (W % 4 == 0 is checked on the host).
 // Table of a cell in the winner selection (see the binning section below): independent of the
 // frame's cell box, so the geometry kernel can already count its pixels per table.
 constexpr int kGeomBinParts = kMaxParts;
@@ -74,23 +75,26 @@ struct PixelGeom {
 };
 
 // depth -> world point -> map cell and height (mapper.py:18-32, 305-311, 851-863, 319-329);
-// dk is the depth after sentinel zeroing, (u, yr) = (column, row - H/2).
-__device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
-                                           float dk, int u, double yr) {
+// dk is the depth after sentinel zeroing, (u, yr) = (column, row - H/2).  FAST uses the verified
+// reciprocal forms above and reports through `sure` whether every step was proven exact.
+template <bool FAST>
+__device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
+                                                float dk, int u, double yr, bool &sure) {
     PixelGeom g;
     const int Hm = mp.map_h, Wm = mp.map_w;
     const bool ok = dk > 0.0f;
     double x = 0.0, y = 0.0, z = 0.0;
     if (ok) {
         z = (double)dk;
-        x = div_known(z * ((double)u - (double)v.W / 2.0), v.fx, v.inv_fx);
-        y = div_known(z * yr, v.fy, v.inv_fy);
+        const double ax = z * ((double)u - (double)v.W / 2.0), ay = z * yr;
+        x = FAST ? div_known(ax, v.fx, v.inv_fx, sure) : ax / v.fx;
+        y = FAST ? div_known(ay, v.fy, v.inv_fy, sure) : ay / v.fy;
     }
     const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
     const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
     const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
-    const double fr = floor_div_known(wz - mp.lower[2], v.p2m, v.inv_p2m);
-    const double fc = floor_div_known(wx - mp.lower[0], v.p2m, v.inv_p2m);
+    const double fr = FAST ? floor_div_known(wz - mp.lower[2], v.inv_p2m, sure) : floor((wz - mp.lower[2]) / v.p2m);
+    const double fc = FAST ? floor_div_known(wx - mp.lower[0], v.inv_p2m, sure) : floor((wx - mp.lower[0]) / v.p2m);
     g.id = kDeadCell;
     g.key = 0;
     g.row = g.col = 0;
@@ -110,6 +114,18 @@ __device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, c
             g.key = order_f64(wy);
         }
     }
+    return g;
+}
+__device__ inline PixelGeom pixel_geometry_exact(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
+                                                       float dk, int u, double yr) {
+    bool unused = true;
+    return pixel_geometry_impl<false>(v, pb, mp, dk, u, yr, unused);
+}
+__device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
+                                           float dk, int u, double yr) {
+    bool sure = true;
+    PixelGeom g = pixel_geometry_impl<true>(v, pb, mp, dk, u, yr, sure);
+    if (!sure) g = pixel_geometry_exact(v, pb, mp, dk, u, yr);   // rare: a quotient too close to call
     return g;
 }
 

@@ -13,6 +13,31 @@
 
 namespace ssmap {
 
+// Wave reductions of the geometry partials without LDS traffic: four DPP row rotations reduce
+// inside each 16-lane row, four lane reads combine the rows.  The cell box travels as two words
+// of packed 16-bit biased coordinates {row, col} and {~row, ~col}, so that one packed minimum
+// reduces two bounds at once (max(x) = ~min(~x)).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_min16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+template <int N>
+__device__ inline uint32_t ror16(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x120 + N, 0xF, 0xF, false);
+}
+__device__ inline uint32_t wave_pk_min16(uint32_t x) {
+    x = pk_min16(x, ror16<8>(x)); x = pk_min16(x, ror16<4>(x)); x = pk_min16(x, ror16<2>(x)); x = pk_min16(x, ror16<1>(x));
+    const uint32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return pk_min16(pk_min16(a, b), pk_min16(c, d));
+}
+__device__ inline uint32_t wave_min_u32(uint32_t x) {
+    x = min(x, ror16<8>(x)); x = min(x, ror16<4>(x)); x = min(x, ror16<2>(x)); x = min(x, ror16<1>(x));
+    const uint32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return min(min(a, b), min(c, d));
+}
+
 __device__ inline int wave_min(int x) {
     for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
     return x;
@@ -41,7 +66,8 @@ __device__ inline double div_known(double a, double b, double rb, bool &sure) {
     const bool plain = ex > 60u && ex < 0x7FEu && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
     const double half_ulp = __builtin_bit_cast(double, (long long)((unsigned long long)(ex - 53u) << 52));
     // a == 0 gives the signed zero a / b gives
-    sure &= (a == 0.0) | (plain & (fabs(r) < half_ulp * fabs(b) * 0.999));
+    // half_ulp is a power of two, so the product on the right is exact and so is the comparison
+    sure &= (a == 0.0) | (plain & (fabs(r) < half_ulp * fabs(b)));
     return a == 0.0 ? q0 : q;
 }
 
@@ -179,23 +205,37 @@ __global__ __launch_bounds__(256) void k_geometry_count(View v, const float *__r
     }
 
     // block reduction of the bbox, the lowest invalid pixel and the error bits
-    __shared__ int s_red[4][6];
-    rmin = wave_min(rmin); rmax = wave_max(rmax);
-    cmin = wave_min(cmin); cmax = wave_max(cmax);
-    min_inv = wave_minu(min_inv);
-    err = (unsigned)wave_max((int)err);
+    __shared__ uint32_t s_red[4][4];
+    const bool any_cell = rmin <= rmax;
+    // biased coordinates fit 14 bits; a thread without cells contributes the neutral 0xFFFF
+    const uint32_t lo = any_cell ? ((uint32_t)(rmin + kCoordBias) << 16) | (uint32_t)(cmin + kCoordBias) : 0xFFFFFFFFu;
+    const uint32_t hi = any_cell ? ((uint32_t)(0xFFFF - (rmax + kCoordBias)) << 16) | (uint32_t)(0xFFFF - (cmax + kCoordBias)) : 0xFFFFFFFFu;
+    const uint32_t w_lo = wave_pk_min16(lo), w_hi = wave_pk_min16(hi);
+    const uint32_t w_inv = wave_min_u32(min_inv);
+    const uint32_t w_err = __ballot(err != 0) ? SSMAP_ENV_INDEX_ERROR : 0u;
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
-        s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
+        s_red[wave][0] = w_lo; s_red[wave][1] = w_hi; s_red[wave][2] = w_inv; s_red[wave][3] = w_err;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t b_lo = s_red[0][0], b_hi = s_red[0][1];
+        min_inv = s_red[0][2];
+        err = s_red[0][3];
         for (int w = 1; w < 4; ++w) {
-            rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
-            cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
-            min_inv = min(min_inv, (unsigned)s_red[w][4]);
-            err |= (unsigned)s_red[w][5];
+            b_lo = pk_min16(b_lo, s_red[w][0]);
+            b_hi = pk_min16(b_hi, s_red[w][1]);
+            min_inv = min(min_inv, s_red[w][2]);
+            err |= s_red[w][3];
+        }
+        if (b_lo == 0xFFFFFFFFu) {   // no cell in this block
+            rmin = cmin = 0x7FFFFFFF;
+            rmax = cmax = (int)0x80000000;
+        } else {
+            rmin = (int)(b_lo >> 16) - kCoordBias;
+            cmin = (int)(b_lo & 0xFFFFu) - kCoordBias;
+            rmax = 0xFFFF - (int)(b_hi >> 16) - kCoordBias;
+            cmax = 0xFFFF - (int)(b_hi & 0xFFFFu) - kCoordBias;
         }
         // per-block partial; k_header_scan folds them (hundreds of blocks hammering one header
         // line with atomics serialise at the memory side)

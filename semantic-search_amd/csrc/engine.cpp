@@ -171,6 +171,8 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
         return fail(SSMAP_ERR_INVALID_ARG, "Invalid num_semantic_classes for height_map_log_odds aggregation");
     if (!(c.pixel2meter > 0) || !(c.fx > 0) || !(c.fy > 0))
         return fail(SSMAP_ERR_INVALID_ARG, "pixel2meter, fx, fy must be positive");
+    if (c.fx < 1e-3 || c.fx > 1e9 || c.fy < 1e-3 || c.fy > 1e9 || c.pixel2meter < 1e-6 || c.pixel2meter > 1e6)
+        return fail(SSMAP_ERR_INVALID_ARG, "fx, fy must lie in [1e-3, 1e9] and pixel2meter in [1e-6, 1e6]");
 
     ssmap_engine *eng = new (std::nothrow) ssmap_engine();
     if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "out of host memory");

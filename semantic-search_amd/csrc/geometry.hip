@@ -63,6 +63,8 @@ __device__ inline double div_known(double a, double b, double rb, bool &sure) {
     const double r = __builtin_fma(-b, q, a);
     const unsigned long long bits = (unsigned long long)__builtin_bit_cast(long long, q);
     const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+    // q must be a normal number away from both ends of the exponent range (half_ulp below is built
+    // from its exponent) and not a power of two (the spacing below a power of two is halved)
     const bool plain = ex > 60u && ex < 0x7FEu && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
     const double half_ulp = __builtin_bit_cast(double, (long long)((unsigned long long)(ex - 53u) << 52));
     // a == 0 gives the signed zero a / b gives

@@ -40,3 +40,25 @@ def test_engine_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         ssa.MapEngine(1, (48, 64), depth_hfov=59.0, depth_range=(0.5, 5.0))
+
+
+def test_create_rejects_configs_before_touching_the_gpu():
+    """Argument checks of ssmap_create run before any HIP call, so they answer on a CPU-only box."""
+    import semantic_search_amd as ssa
+    c = ssa._capi
+    lib = c.load()
+
+    def cfg(**over):
+        kw = dict(n_envs=1, img_h=48, img_w=64, n_classes=8, n_schema=9, rule=c.RULES["avg_prob"],
+                  use_height_map=1, max_map_h=100, max_map_w=100, depth_min=0.5, depth_max=5.0,
+                  fx=56.0, fy=56.0, pixel2meter=0.03, height_cutoff_m=0.1)
+        kw.update(over)
+        return c.Config(**kw)
+
+    for bad, text in ((dict(img_w=62), "multiple of 4"), (dict(fx=1e12), "fx, fy"), (dict(pixel2meter=0.0), "positive"),
+                      (dict(rule=99), "prob_aggregate"), (dict(max_map_w=9000), "map dimensions")):
+        handle = ctypes.c_void_p()
+        rc = lib.ssmap_create(ctypes.byref(cfg(**bad)), ctypes.byref(handle))
+        assert rc != 0 and not handle.value, bad
+        assert text in lib.ssmap_last_error().decode(), (bad, lib.ssmap_last_error())
+    assert ctypes.sizeof(c.EgomapConfig) == 8 * 4 + 2 * c.MAX_AUX * 4 + 8

@@ -6,11 +6,12 @@
 // (lane <-> pixel, so one wave-load reads 256 contiguous bytes of one class plane) and kept
 //   * in registers when C is one of the compiled sizes (kernel k_stream_reg), or
 //   * in a private LDS column of stride 257 floats otherwise (kernel k_stream_lds).
-// Pixels that won a map cell (target[pix] = their slot in the frame's update list, written by
-// the winner kernel) copy their probability vector to row `slot` of a compact [K][C] buffer;
-// the streaming pass never waits on map memory.  k_update_prob then gives every update cell
-// to a wave, lanes over the classes: the read-modify-write of the cell's C contiguous floats
-// in the fused map is coalesced and the per-cell entropy / argmax are wavefront reductions.
+// Pixels that own a map cell this step (wflag[pix] set by the winner kernel, target[pix] = their
+// slot in the frame's update list) hand their probability vector, staged through LDS, to row
+// `slot` of a compact [K][C] buffer; the streaming pass never waits on map memory.
+// k_update_prob then gives every update cell to a 16-lane row of a wave, lanes over the classes:
+// the read-modify-write of the cell's C contiguous floats in the fused map is coalesced and the
+// per-cell entropy / argmax are DPP row reductions.
 #include "ssmap_internal.h"
 #include "rows.h"
 

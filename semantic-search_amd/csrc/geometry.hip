@@ -732,7 +732,7 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     }
 }
 
-// Frames whose padded cell box fits the 16 tables are binned (k_header_scan, k_bin_scatter) and
+// Frames whose padded cell box fits the 16 tables are binned (k_header_scan, k_geometry_scatter) and
 // read as contiguous record ranges; larger boxes fall back to scanning every cell id once per table.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
     __shared__ WinnerShared sh;

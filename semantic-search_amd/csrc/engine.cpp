@@ -349,6 +349,7 @@ static bool build_ego_axis(EgoTables &t, EgoAxis &ax, int ssize, int dsize, int 
             sx1 = std::min(sx1, sx2);
             auto push = [&](int si, double w) {
                 if (pool >= kEgoTapPool) return false;
+                if (ax.count[d] >= 8) return false;   // kEgoMaxTaps of the kernel
                 t.tap_src[pool] = si;
                 t.tap_w[pool] = (float)w;
                 ++pool;
@@ -395,6 +396,8 @@ int ssmap_set_egomap(ssmap_engine *eng, const ssmap_egomap_config *cfg) {
     const std::vector<int32_t> hw = disk_halfwidths(c.agent_radius_px);
     for (int i = 0; i <= c.agent_radius_px; ++i) t.agent_hw[i] = hw[i];
     memcpy(t.aux_points, c.aux_points, sizeof(int32_t) * 2 * c.n_aux);
+    t.aux_reach = 0;
+    for (int i = 0; i < 2 * c.n_aux; ++i) t.aux_reach = std::max(t.aux_reach, std::abs(c.aux_points[i]) + t.aux_half + 1);
     memcpy(t.active_goal_color, c.active_goal_color, 3);
     memcpy(t.arrow_color, c.arrow_color, 3);
     int pool = 0;

@@ -151,7 +151,8 @@ struct EgoAxis {
 struct EgoTables {
     int32_t side, origin, out_w, out_h;
     int32_t crop_off[2], mode[2];       // [0] small crop, [1] large crop
-    int32_t agent_radius, aux_half, n_aux, pad;
+    int32_t agent_radius, aux_half, n_aux;
+    int32_t aux_reach;                  // no auxiliary square reaches further from the centre than this
     int32_t agent_hw[kEgoMaxRadius + 1];
     int32_t aux_points[2 * SSMAP_MAX_AUX];
     uint8_t active_goal_color[4], arrow_color[4];

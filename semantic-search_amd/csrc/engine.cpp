@@ -126,6 +126,30 @@ struct ssmap_engine {
 
 constexpr int kProfMarks = 6;   // 5 stage intervals
 
+// Cell box that holds every pixel of a frame whose depth is at most depth_max: the camera position
+// and the four far corners of the view pyramid span it (world = R p + t is linear in the camera
+// point), padded by two cells and cut to the range numpy can index, [-dim, dim).  A container only:
+// a pixel outside it makes the kernels take their scanning path, never a wrong result.
+static void predict_box(const ssmap_config &c, const ssmap_env_maps &mp, PoseBlock &b) {
+    const double xs[2] = {(0.0 - c.img_w / 2.0) / c.fx, ((c.img_w - 1) - c.img_w / 2.0) / c.fx};
+    const double ys[2] = {(0.0 - c.img_h / 2.0) / c.fy, ((c.img_h - 1) - c.img_h / 2.0) / c.fy};
+    const double z = c.depth_max;
+    double lo_x = b.trans[0], hi_x = b.trans[0], lo_z = b.trans[2], hi_z = b.trans[2];
+    for (int i = 0; i < 4; ++i) {
+        const double x = z * xs[i & 1], y = z * ys[i >> 1];
+        const double wx = b.rot[0] * x + b.rot[1] * y + b.rot[2] * z + b.trans[0];
+        const double wz = b.rot[6] * x + b.rot[7] * y + b.rot[8] * z + b.trans[2];
+        lo_x = std::min(lo_x, wx); hi_x = std::max(hi_x, wx);
+        lo_z = std::min(lo_z, wz); hi_z = std::max(hi_z, wz);
+    }
+    const auto cell = [&](double w, double lb) { return clamp_cell(std::floor((w - lb) / c.pixel2meter)); };
+    b.box[0] = std::max(cell(lo_z, mp.lower[2]) - 2, -mp.map_h);
+    b.box[1] = std::min(cell(hi_z, mp.lower[2]) + 2, mp.map_h - 1);
+    b.box[2] = std::max(cell(lo_x, mp.lower[0]) - 2, -mp.map_w);
+    b.box[3] = std::min(cell(hi_x, mp.lower[0]) + 2, mp.map_w - 1);
+    if (b.box[0] > b.box[1] || b.box[2] > b.box[3]) { b.box[0] = b.box[2] = 0; b.box[1] = b.box[3] = -1; }
+}
+
 extern "C" {
 
 const char *ssmap_last_error(void) { return g_error.c_str(); }
@@ -135,7 +159,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.cellid); hipFree(v.horder); hipFree(v.rec_h); hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.part_start); hipFree(v.target); hipFree(v.wflag); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
+    hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.rec_h); hipFree(v.rec_w); hipFree(v.rec_s); hipFree(v.target); hipFree(v.wflag); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
     hipFree(v.local_ids); hipFree(v.local_eroded);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
@@ -194,15 +218,14 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_envs, (size_t)v.E));
     TRY_ALLOC(dev_alloc(&eng->d_poses, (size_t)v.E));
     TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
-    TRY_ALLOC(dev_alloc(&v.cellid, EN));
-    TRY_ALLOC(dev_alloc(&v.horder, EN));
-    TRY_ALLOC(dev_alloc(&v.geo_part, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * 8));
-    TRY_ALLOC(dev_alloc(&v.rec_h, EN * 2));   // height images, then the record words, then the slots
-    v.rec_w = reinterpret_cast<uint32_t *>(v.rec_h + EN);
-    v.rec_s = v.rec_w + EN;
+    v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
-    TRY_ALLOC(dev_alloc(&v.bin_cnt, (size_t)v.E * ((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock) * kMaxParts));
-    TRY_ALLOC(dev_alloc(&v.part_start, (size_t)v.E * (kMaxParts + 1)));
+    const size_t n_rec = (size_t)v.E * kMaxParts * v.geom_blocks * kGeomPixPerBlock;
+    TRY_ALLOC(dev_alloc(&v.geo_part, (size_t)v.E * v.geom_blocks));
+    TRY_ALLOC(dev_alloc(&v.bin_cnt, (size_t)v.E * kMaxParts * v.geom_blocks));
+    TRY_ALLOC(dev_alloc(&v.rec_h, n_rec));
+    TRY_ALLOC(dev_alloc(&v.rec_w, n_rec));
+    if (!v.rec_packed) TRY_ALLOC(dev_alloc(&v.rec_s, n_rec));
     if (prob_rule) {
         TRY_ALLOC(dev_alloc(&v.target, EN));
         TRY_ALLOC(dev_alloc(&v.wflag, EN));
@@ -532,6 +555,7 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         b.robot_col = clamp_cell(std::floor((ag[0] - mp.lower[0]) / c.pixel2meter));
         b.goal_id = f->goal_sem_id[e];
         b.pad = 0;
+        predict_box(c, mp, b);
     }
 
     if (!packed) {

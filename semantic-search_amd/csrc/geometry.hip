@@ -157,98 +157,6 @@ __device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, c
     return g;
 }
 
-// The geometry runs twice over the depth image instead of parking 12 bytes per pixel in HBM
-// between a counting and a scattering kernel:
-//   k_geometry_count    cells only: per-block pixel counts per winner table, per-block partials of
-//                       the cell box / lowest invalid pixel / error bits.  No per-pixel output.
-//   (k_header_scan      frame header, prefix sums)
-//   k_geometry_scatter  the same arithmetic again; zeroes the depth sentinels in place, clears the
-//                       owner flags and writes each live pixel's 12-byte record straight into its
-//                       table's range (or, for a frame too large to bin, cell ids and heights
-//                       per pixel for the scanning winner kernel).
-// PACKED: the poses arrive as a kernel argument (batches of at most kPosePack envs: no
-// host-to-device copy in front of the step) and block 0 of every env stores its pose for the
-// later kernels; otherwise the poses are already in v.poses.
-template <bool PACKED>
-__global__ __launch_bounds__(256) void k_geometry_count(View v, const float *__restrict__ depth_all, PosePack pack) {
-    const int e = blockIdx.y;
-    const int64_t fbase = (int64_t)e * v.N;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const PoseBlock &pb = PACKED ? pack.p[blockIdx.y] : v.poses[e];
-    if (PACKED && blockIdx.x == 0 && threadIdx.x < sizeof(PoseBlock) / 8)
-        reinterpret_cast<double *>(v.poses + e)[threadIdx.x] = reinterpret_cast<const double *>(&pb)[threadIdx.x];
-    const ssmap_env_maps &mp = v.envs[e].maps;
-
-    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
-    unsigned min_inv = kNoPixel;
-    unsigned err = 0;
-    __shared__ unsigned int s_tab[kGeomBinParts];   // live pixels of this block per winner table
-    if (threadIdx.x < kGeomBinParts) s_tab[threadIdx.x] = 0;
-    __syncthreads();
-
-    if (i0 < v.N) {
-        const int r = i0 / v.W;
-        const int c0 = i0 - r * v.W;
-        const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
-        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
-        const double yr = (double)r - (double)v.H / 2.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float dk = (d[k] == v.depth_min || d[k] == v.depth_max) ? 0.0f : d[k];   // mapper.py:279-283
-            const PixelGeom g = pixel_geometry(v, pb, mp, dk, c0 + k, yr);
-            if (g.in_box) {
-                rmin = min(rmin, g.row); rmax = max(rmax, g.row);
-                cmin = min(cmin, g.col); cmax = max(cmax, g.col);
-            }
-            if (g.index_error) err |= SSMAP_ENV_INDEX_ERROR;
-            if (g.invalid) min_inv = min(min_inv, (unsigned)(i0 + k));
-            if (g.id != kDeadCell) atomicAdd(&s_tab[geom_cell_table(g.id)], 1u);
-        }
-    }
-
-    // block reduction of the bbox, the lowest invalid pixel and the error bits
-    __shared__ uint32_t s_red[4][4];
-    const bool any_cell = rmin <= rmax;
-    // biased coordinates fit 14 bits; a thread without cells contributes the neutral 0xFFFF
-    const uint32_t lo = any_cell ? ((uint32_t)(rmin + kCoordBias) << 16) | (uint32_t)(cmin + kCoordBias) : 0xFFFFFFFFu;
-    const uint32_t hi = any_cell ? ((uint32_t)(0xFFFF - (rmax + kCoordBias)) << 16) | (uint32_t)(0xFFFF - (cmax + kCoordBias)) : 0xFFFFFFFFu;
-    const uint32_t w_lo = wave_pk_min16(lo), w_hi = wave_pk_min16(hi);
-    const uint32_t w_inv = wave_min_u32(min_inv);
-    const uint32_t w_err = __ballot(err != 0) ? SSMAP_ENV_INDEX_ERROR : 0u;
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_red[wave][0] = w_lo; s_red[wave][1] = w_hi; s_red[wave][2] = w_inv; s_red[wave][3] = w_err;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t b_lo = s_red[0][0], b_hi = s_red[0][1];
-        min_inv = s_red[0][2];
-        err = s_red[0][3];
-        for (int w = 1; w < 4; ++w) {
-            b_lo = pk_min16(b_lo, s_red[w][0]);
-            b_hi = pk_min16(b_hi, s_red[w][1]);
-            min_inv = min(min_inv, s_red[w][2]);
-            err |= s_red[w][3];
-        }
-        if (b_lo == 0xFFFFFFFFu) {   // no cell in this block
-            rmin = cmin = 0x7FFFFFFF;
-            rmax = cmax = (int)0x80000000;
-        } else {
-            rmin = (int)(b_lo >> 16) - kCoordBias;
-            cmin = (int)(b_lo & 0xFFFFu) - kCoordBias;
-            rmax = 0xFFFF - (int)(b_hi >> 16) - kCoordBias;
-            cmax = 0xFFFF - (int)(b_hi & 0xFFFFu) - kCoordBias;
-        }
-        // per-block partial; k_header_scan folds them (hundreds of blocks hammering one header
-        // line with atomics serialise at the memory side)
-        int *part = v.geo_part + ((int64_t)e * gridDim.x + blockIdx.x) * 8;
-        *reinterpret_cast<int4 *>(part) = make_int4(rmin, rmax, cmin, cmax);
-        *reinterpret_cast<int4 *>(part + 4) = make_int4((int)min_inv, (int)err, 0, 0);
-    }
-    if (threadIdx.x < kGeomBinParts)   // layout [table][block]; the barrier above covers the LDS adds
-        v.bin_cnt[((int64_t)e * kGeomBinParts + threadIdx.x) * gridDim.x + blockIdx.x] = s_tab[threadIdx.x];
-}
-
 // Binning: the live pixels of a frame are sorted by winner table into contiguous arrays of
 // 12-byte records {height image, slot << 19 | pixel} so that a winner-table block reads only its
 // own records instead of every pixel of the frame.  The geometry kernel already counts its
@@ -302,147 +210,155 @@ __device__ inline void slot_cell(const BinFrame &f, int table, int slot, int &ro
     col = (((f.cc0 + j) << kChunkShift) | (slot & kChunkMask)) - kCoordBias;
 }
 
-// One block per frame: folds the geometry blocks' partials into the frame header, resets the
-// per-step counters, and turns the per-block table counts bin_cnt[p][b] into the first record
-// index of block b's pixels for table p; part_start[p] = first record of table p.
-__global__ __launch_bounds__(1024) void k_header_scan(View v, int nbin) {
-    __shared__ unsigned int total[kBinParts + 1];
-    __shared__ int s_red[16][6];
-    __shared__ FrameHeader s_hdr;
-    const int e = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
-        unsigned min_inv = kNoPixel, err = 0;
-        for (int b = threadIdx.x; b < nbin; b += blockDim.x) {
-            const int *part = v.geo_part + ((int64_t)e * nbin + b) * 8;
-            const int4 a = *reinterpret_cast<const int4 *>(part);
-            const int4 c = *reinterpret_cast<const int4 *>(part + 4);
-            rmin = min(rmin, a.x); rmax = max(rmax, a.y); cmin = min(cmin, a.z); cmax = max(cmax, a.w);
-            min_inv = min(min_inv, (unsigned)c.x);
-            err |= (unsigned)c.y;
-        }
-        rmin = wave_min(rmin); rmax = wave_max(rmax);
-        cmin = wave_min(cmin); cmax = wave_max(cmax);
-        min_inv = wave_minu(min_inv);
-        for (int o = 32; o > 0; o >>= 1) err |= (unsigned)__shfl_xor((int)err, o);
-        if (lane == 0) {
-            s_red[wave][0] = rmin; s_red[wave][1] = rmax; s_red[wave][2] = cmin; s_red[wave][3] = cmax;
-            s_red[wave][4] = (int)min_inv; s_red[wave][5] = (int)err;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 16; ++w) {
-                rmin = min(rmin, s_red[w][0]); rmax = max(rmax, s_red[w][1]);
-                cmin = min(cmin, s_red[w][2]); cmax = max(cmax, s_red[w][3]);
-                min_inv = min(min_inv, (unsigned)s_red[w][4]);
-                err |= (unsigned)s_red[w][5];
-            }
+// One pass over the depth image.  The host predicts a cell box that contains every live pixel of
+// the frame (the camera frustum up to depth_max, padded); cell slots are dense over that box, so
+// nothing about the frame has to be known before the records are written, and no block waits
+// for another:
+//   * a block owns kGeomPixPerBlock record places in every winner table; a live pixel takes the
+//     next free place of its table (LDS counter) and its 12-byte record is written at once; the
+//     block's counts go to bin_cnt;
+//   * the depth sentinels are zeroed in place and the owner flags cleared on the way;
+//   * the block's lowest invalid pixel and error bits go to its report (GeomPart);
+//   * a live pixel outside the predicted box (a depth above depth_max, a box too large to bin)
+//     marks the report as spilled and widens its box: the winner kernel then ignores the tables of
+//     that frame and scans the pixels instead.
+// Block 0 of every env also writes the step's frame header and, when the poses travel as a kernel
+// argument (POSE_ARG, at most kPosePack envs), stores the env's pose for the later kernels.
+// PACKED: slot and pixel share one record word (frames of at most 2^kPackPixBits pixels).
+__device__ inline BinFrame bin_frame_box(const int32_t *box) {
+    BinFrame f;
+    f.on = false;
+    const int rmin = box[0], rmax = box[1], cmin = box[2], cmax = box[3];
+    if (rmin > rmax || cmin > cmax) return f;
+    f.rmin_b = rmin + kCoordBias;
+    f.cc0 = (cmin + kCoordBias) >> kChunkShift;
+    const int cc1 = (cmax + kCoordBias) >> kChunkShift;
+    f.per_row = (cc1 - f.cc0 + kBinParts) >> kBinShift;
+    f.on = ((long long)(rmax - rmin + 1) * f.per_row << kChunkShift) <= kSlots;
+    return f;
+}
+
+// Place `place` of geometry block b's share of table `part`.  Shares are stored in rows of 64
+// records, [place / 64][e][part][b][place % 64]: row 0 of all shares, which holds nearly all
+// records, is one dense range of memory, row 1 the next, instead of one short run every
+// kGeomPixPerBlock records.
+__device__ inline int64_t rec_table_base(const View &v, int e, int part) {
+    return ((int64_t)e * kBinParts + part) * v.geom_blocks * 64;
+}
+__device__ inline int64_t rec_offset(const View &v, int b, unsigned place) {
+    const int64_t row_stride = (int64_t)v.E * kBinParts * v.geom_blocks * 64;
+    return (int64_t)(place >> 6) * row_stride + (int64_t)(((unsigned)b << 6) | (place & 63u));
+}
+
+template <bool POSE_ARG, bool PACKED>
+__global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all, PosePack pack, int write_target) {
+    __shared__ unsigned int s_cnt[kBinParts];
+    __shared__ unsigned int s_inv, s_err, s_spill;
+    __shared__ int s_box[4];
+    const int e = blockIdx.y;
+    const int64_t fbase = (int64_t)e * v.N;
+    const PoseBlock &pb = POSE_ARG ? pack.p[blockIdx.y] : v.poses[e];
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    if (blockIdx.x == 0) {
+        if (POSE_ARG && threadIdx.x < sizeof(PoseBlock) / 8)
+            reinterpret_cast<double *>(v.poses + e)[threadIdx.x] = reinterpret_cast<const double *>(&pb)[threadIdx.x];
+        if (threadIdx.x == 64) {
             FrameHeader h;
-            h.rmin = rmin; h.rmax = rmax; h.cmin = cmin; h.cmax = cmax;
+            h.rmin = pb.box[0]; h.rmax = pb.box[1]; h.cmin = pb.box[2]; h.cmax = pb.box[3];
             h.wrmin = h.wcmin = 0x7FFFFFFF;
             h.wrmax = h.wcmax = (int32_t)0x80000000;
-            h.min_invalid_pixel = min_inv;
+            h.min_invalid_pixel = kNoPixel;
             h.n_winners = 0;
-            h.status = err;
+            h.status = 0;
             h.found = 0;
             h.any_goal = 0;
             h.n_overlay = 0;
             h.n_neg = 0;
             h.pad = 0;
-            s_hdr = h;
             v.hdr[e] = h;
             v.overlay_count[v.cur_overlay][e] = 0;
         }
-        __syncthreads();
     }
-    if (!bin_frame(&s_hdr).on) return;
-    unsigned int *cnt = v.bin_cnt + (int64_t)e * kBinParts * nbin;
-    {
-        const int p = wave;       // 16 waves, 16 tables
-        unsigned sum = 0;
-        for (int b = lane; b < nbin; b += 64) sum += cnt[p * nbin + b];
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) total[p] = sum;
+    const int rmin = pb.box[0], rmax = pb.box[1], cmin = pb.box[2], cmax = pb.box[3];
+    const BinFrame f = bin_frame_box(pb.box);
+    if (threadIdx.x < kBinParts) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 64) {
+        s_inv = kNoPixel; s_err = 0; s_spill = 0;
+        s_box[0] = s_box[2] = 0x7FFFFFFF;
+        s_box[1] = s_box[3] = (int)0x80000000;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int p = 0; p < kBinParts; ++p) { const unsigned c = total[p]; total[p] = run; run += c; }
-        total[kBinParts] = run;
-    }
-    __syncthreads();
-    if (threadIdx.x <= kBinParts) v.part_start[e * (kBinParts + 1) + threadIdx.x] = total[threadIdx.x];
-    {
-        const int p = wave;
-        unsigned run = total[p];
-        for (int b0 = 0; b0 < nbin; b0 += 64) {
-            const int b = b0 + lane;
-            const unsigned c = b < nbin ? cnt[p * nbin + b] : 0u;
-            unsigned incl = c;   // inclusive wave scan
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
-            }
-            if (b < nbin) cnt[p * nbin + b] = run + incl - c;
-            run += __shfl(incl, 63);
-        }
-    }
-}
 
-template <bool PACKED>
-__global__ __launch_bounds__(256) void k_geometry_scatter(View v, float *__restrict__ depth_all, int write_target) {
-    __shared__ unsigned int cnt[kBinParts];
-    __shared__ unsigned int base[kBinParts];
-    const int e = blockIdx.y;
-    const int64_t fbase = (int64_t)e * v.N;
-    const PoseBlock &pb = v.poses[e];
-    const ssmap_env_maps &mp = v.envs[e].maps;
-    const BinFrame f = bin_frame(v.hdr + e);
-    if (threadIdx.x < kBinParts) {
-        cnt[threadIdx.x] = 0;
-        base[threadIdx.x] = f.on ? v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x] : 0u;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned min_inv = kNoPixel, err = 0;
+    int srmin = 0x7FFFFFFF, srmax = (int)0x80000000, scmin = 0x7FFFFFFF, scmax = (int)0x80000000;
+    bool spill = false;
+    if (i0 < v.N) {
+        const int r = i0 / v.W;
+        const int c0 = i0 - r * v.W;
+        const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const double yr = (double)r - (double)v.H / 2.0;
+        bool dirty = false;
+        uint32_t part_slot[4];          // table << 16 | slot, or kDeadCell
+        unsigned long long hk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (d[k] == v.depth_min || d[k] == v.depth_max) { d[k] = 0.0f; dirty = true; }   // mapper.py:279-283
+            const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
+            hk[k] = g.key;
+            part_slot[k] = kDeadCell;
+            if (g.index_error) err |= SSMAP_ENV_INDEX_ERROR;
+            if (g.invalid) min_inv = min(min_inv, (unsigned)(i0 + k));
+            if (g.id == kDeadCell) continue;
+            if (f.on && g.row >= rmin && g.row <= rmax && g.col >= cmin && g.col <= cmax) {
+                part_slot[k] = ((uint32_t)cell_table(g.id) << 16) | (uint32_t)cell_slot(f, g.id);
+            } else {
+                spill = true;
+                srmin = min(srmin, g.row); srmax = max(srmax, g.row);
+                scmin = min(scmin, g.col); scmax = max(scmax, g.col);
+            }
+        }
+        if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
+        if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (part_slot[k] == kDeadCell) continue;
+            const int part = (int)(part_slot[k] >> 16);
+            const unsigned slot = part_slot[k] & 0xFFFFu;
+            // at most kGeomPixPerBlock live pixels in a block: the place is inside the block's share
+            const unsigned place = atomicAdd(&s_cnt[part], 1u);
+            const int64_t at = rec_table_base(v, e, part) + rec_offset(v, blockIdx.x, place);
+            v.rec_h[at] = hk[k];
+            if (PACKED) {
+                v.rec_w[at] = (slot << kPackPixBits) | (unsigned)(i0 + k);
+            } else {
+                v.rec_w[at] = (unsigned)(i0 + k);
+                v.rec_s[at] = slot;
+            }
+        }
+    }
+    // the block's report
+    const uint32_t w_inv = wave_min_u32(min_inv);
+    if ((threadIdx.x & 63) == 0 && w_inv != kNoPixel) atomicMin(&s_inv, w_inv);
+    if (__ballot(err != 0) && (threadIdx.x & 63) == 0) s_err = SSMAP_ENV_INDEX_ERROR;
+    if (__ballot(spill)) {
+        srmin = wave_min(srmin); srmax = wave_max(srmax);
+        scmin = wave_min(scmin); scmax = wave_max(scmax);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_box[0], srmin); atomicMax(&s_box[1], srmax);
+            atomicMin(&s_box[2], scmin); atomicMax(&s_box[3], scmax);
+            s_spill = 1u;
+        }
     }
     __syncthreads();
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= v.N) return;
-    const int r = i0 / v.W;
-    const int c0 = i0 - r * v.W;
-    const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
-    float d[4] = {d4.x, d4.y, d4.z, d4.w};
-    const double yr = (double)r - (double)v.H / 2.0;
-    bool dirty = false;
-    uint32_t ids[4];
-    unsigned long long hk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (d[k] == v.depth_min || d[k] == v.depth_max) { d[k] = 0.0f; dirty = true; }
-        const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
-        ids[k] = g.id;
-        hk[k] = g.key;
-    }
-    if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
-    if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
-    if (!f.on) {
-        // not binned: the scanning winner kernel reads cell id and height per pixel
-        *reinterpret_cast<uint4 *>(v.cellid + fbase + i0) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
-        unsigned long long *hp = v.horder + fbase + i0;
-        *reinterpret_cast<ulonglong2 *>(hp) = make_ulonglong2(hk[0], hk[1]);
-        *reinterpret_cast<ulonglong2 *>(hp + 2) = make_ulonglong2(hk[2], hk[3]);
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (ids[k] == kDeadCell) continue;
-        const int part = cell_table(ids[k]), slot = cell_slot(f, ids[k]);
-        const unsigned pos = base[part] + atomicAdd(&cnt[part], 1u);
-        v.rec_h[fbase + pos] = hk[k];
-        if (PACKED) {
-            v.rec_w[fbase + pos] = ((unsigned)slot << kPackPixBits) | (unsigned)(i0 + k);
-        } else {
-            v.rec_w[fbase + pos] = (unsigned)(i0 + k);
-            v.rec_s[fbase + pos] = (unsigned)slot;
-        }
+    if (threadIdx.x < kBinParts)
+        v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x == 64) {
+        GeomPart part;
+        part.min_invalid_pixel = s_inv; part.err = s_err; part.spill = s_spill; part.pad = 0;
+        part.rmin = s_box[0]; part.rmax = s_box[1]; part.cmin = s_box[2]; part.cmax = s_box[3];
+        v.geo_part[(int64_t)e * gridDim.x + blockIdx.x] = part;
     }
 }
 
@@ -453,13 +369,53 @@ __global__ __launch_bounds__(256) void k_geometry_scatter(View v, float *__restr
 //   phase b   table_i[slot] = min pixel index among the pixels that reach that max
 //   phase c   slots whose winner passes the filters are appended to the update list
 // Integer max / min are order independent, so the result is deterministic.
+// A wave of the winner kernel takes every 16th geometry block, one lane per block for the
+// bookkeeping: frames of more than 1024 blocks (a million pixels) take the scanning path.
+constexpr int kMaxGeomBlocksBinned = (kWinnerThreads / 64) * 64;
 struct WinnerShared {
     unsigned long long table_h[kSlots];
     unsigned int table_i[kSlots];
     unsigned int s_base, s_neg;
     unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
     int s_box[kWinnerThreads / 64][4];
+    GeomPart frame;                        // the geometry blocks' reports, folded
+    unsigned int s_tail[kWinnerThreads / 64][64];   // per wave: tail records in front of each of its blocks
 };
+
+// Folds the reports of the frame's geometry blocks (every winner block does it for itself).
+__device__ inline void fold_reports(const View &v, int e, WinnerShared &sh) {
+    unsigned min_inv = kNoPixel, flags = 0;
+    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
+    for (int b = threadIdx.x; b < v.geom_blocks; b += kWinnerThreads) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(v.geo_part + (int64_t)e * v.geom_blocks + b);
+        const uint4 a = q[0], c = q[1];
+        min_inv = min(min_inv, a.x);
+        flags |= a.y | (a.z ? 0x80000000u : 0u);
+        rmin = min(rmin, (int)c.x); rmax = max(rmax, (int)c.y);
+        cmin = min(cmin, (int)c.z); cmax = max(cmax, (int)c.w);
+    }
+    if (threadIdx.x == 0) {
+        sh.frame.min_invalid_pixel = kNoPixel; sh.frame.err = 0; sh.frame.spill = 0; sh.frame.pad = 0;
+        sh.frame.rmin = sh.frame.cmin = 0x7FFFFFFF;
+        sh.frame.rmax = sh.frame.cmax = (int)0x80000000;
+    }
+    __syncthreads();
+    min_inv = wave_min_u32(min_inv);
+    rmin = wave_min(rmin); rmax = wave_max(rmax);
+    cmin = wave_min(cmin); cmax = wave_max(cmax);
+    const bool any_flag = __ballot(flags != 0) != 0ull;
+    for (int o = 32; o > 0 && any_flag; o >>= 1) flags |= (unsigned)__shfl_xor((int)flags, o);
+    if ((threadIdx.x & 63) == 0) {
+        if (min_inv != kNoPixel) atomicMin(&sh.frame.min_invalid_pixel, min_inv);
+        if (flags & 0x7FFFFFFFu) atomicOr(&sh.frame.err, flags & 0x7FFFFFFFu);
+        if (flags & 0x80000000u) sh.frame.spill = 1u;
+        if (rmin <= rmax) {
+            atomicMin(&sh.frame.rmin, rmin); atomicMax(&sh.frame.rmax, rmax);
+            atomicMin(&sh.frame.cmin, cmin); atomicMax(&sh.frame.cmax, cmax);
+        }
+    }
+    __syncthreads();
+}
 
 // One binned record in registers.  The not-updatable flag is not stored: a pixel in a table has
 // valid depth and lies inside the upper bounds, so it is updatable exactly when its height is
@@ -481,25 +437,26 @@ struct Rec<false> {
     __device__ uint32_t word() const { return w << 1; }
 };
 template <bool PACKED>
-__device__ inline Rec<PACKED> load_rec(const View &v, int64_t fbase, unsigned t);
+__device__ inline Rec<PACKED> load_rec(const View &v, int64_t at);
 template <>
-__device__ inline Rec<true> load_rec<true>(const View &v, int64_t fbase, unsigned t) {
+__device__ inline Rec<true> load_rec<true>(const View &v, int64_t at) {
     Rec<true> r;
-    r.h = v.rec_h[fbase + t];
-    r.w = v.rec_w[fbase + t];
+    r.h = v.rec_h[at];
+    r.w = v.rec_w[at];
     return r;
 }
 template <>
-__device__ inline Rec<false> load_rec<false>(const View &v, int64_t fbase, unsigned t) {
+__device__ inline Rec<false> load_rec<false>(const View &v, int64_t at) {
     Rec<false> r;
-    r.h = v.rec_h[fbase + t];
-    r.w = v.rec_w[fbase + t];
-    r.s = v.rec_s[fbase + t];
+    r.h = v.rec_h[at];
+    r.w = v.rec_w[at];
+    r.s = v.rec_s[at];
     return r;
 }
 
 template <bool RUNS, bool PACKED>
-__device__ __forceinline__ void winners_body(const View &v, int write_target, int write_list, WinnerShared &sh) {
+__device__ __forceinline__ void winners_body(const View &v, const float *__restrict__ depth_all, int write_target,
+                                             int write_list, WinnerShared &sh) {
     unsigned long long (&table_h)[kSlots] = sh.table_h;
     unsigned int (&table_i)[kSlots] = sh.table_i;
     unsigned int &s_base = sh.s_base, &s_neg = sh.s_neg;
@@ -509,8 +466,17 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
     FrameHeader *hdr = v.hdr + e;
-    const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
-    if (rmin > rmax) return;
+    const GeomPart *acc = &sh.frame;
+    int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
+    if (!RUNS) {
+        // scanned frame: the cells lie in the box of the spilled pixels, joined with the predicted
+        // box when that one was in use (its pixels were not accumulated)
+        const bool pred = bin_frame(hdr).on;
+        if (!pred) { rmin = cmin = 0x7FFFFFFF; rmax = cmax = (int)0x80000000; }
+        rmin = min(rmin, acc->rmin); rmax = max(rmax, acc->rmax);
+        cmin = min(cmin, acc->cmin); cmax = max(cmax, acc->cmax);
+    }
+    if (rmin > rmax || cmin > cmax) return;
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
     const int Hm = mp.map_h, Wm = mp.map_w;
@@ -522,7 +488,7 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 
     // the cell all invalid-depth pixels fall into (they sit at the camera position,
     // mapper.py:28-31) and their common height
-    const unsigned min_inv = hdr->min_invalid_pixel;
+    const unsigned min_inv = acc->min_invalid_pixel;
     long long inv_L = -1;
     unsigned long long inv_key = 0;
     if (min_inv != kNoPixel) {
@@ -548,19 +514,46 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
             inv_slot = (int)(inv_L & (kSlots - 1));
         }
     }
-    const uint4 *ids4 = reinterpret_cast<const uint4 *>(v.cellid + fbase);
-    const unsigned long long *hk = v.horder + fbase;
+    const float4 *depth4 = reinterpret_cast<const float4 *>(depth_all + fbase);   // sentinels already zeroed
     const int n4 = v.N >> 2;
-    // binned records of this frame, contiguous per table
-    const unsigned int *part_start = v.part_start + e * (kMaxParts + 1);
-    constexpr int kRunBatch = 4;
+    constexpr int kWaves = kWinnerThreads / 64;
     constexpr int kKeep = RUNS ? (PACKED ? 19 : 14) : 1;   // records per thread kept in registers between the phases
-    Rec<PACKED> keep[kKeep];
+    Rec<PACKED> keep[kKeep], tail0;
     int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
     if (threadIdx.x == 0) s_neg = 0;
 
     for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
-        const unsigned rec_beg = RUNS ? part_start[p] : 0u, rec_end = RUNS ? part_start[p + 1] : 0u;
+        // Binned records of this table: geometry block b left bin_cnt[b] of them in its share, in
+        // rows of 64.  Wave w takes the blocks w, w + 16, ...; lane l keeps the books of the l-th
+        // of them.  Row 0 of the wave's first kKeep blocks is read one lane per record and stays in
+        // registers between the phases; everything else (the few records beyond 64 of those
+        // blocks, later blocks) forms the wave's tail, numbered through a prefix sum.
+        const int nb = v.geom_blocks;
+        const int64_t tbase = rec_table_base(v, e, p);
+        const int wave_id = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+        unsigned cvec = 0, tail_total = 0;
+        if (RUNS) {
+            const unsigned int *cnt = v.bin_cnt + ((int64_t)e * kBinParts + p) * nb;
+            const int b = wave_id + kWaves * lane_id;
+            cvec = b < nb ? min(cnt[b], (unsigned)kGeomPixPerBlock) : 0u;
+            const unsigned tn = lane_id < kKeep ? (cvec > 64u ? cvec - 64u : 0u) : cvec;
+            unsigned incl = tn;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (lane_id >= o) incl += up;
+            }
+            sh.s_tail[wave_id][lane_id] = incl - tn;
+            tail_total = __shfl(incl, 63);
+        }
+        // place of tail record i of this wave (i < tail_total); read after the barrier below
+        auto tail_offset = [&](unsigned i) -> int64_t {
+            int lo = 0, hi = 64;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (i >= sh.s_tail[wave_id][mid]) lo = mid; else hi = mid;
+            }
+            return rec_offset(v, wave_id + kWaves * lo, (lo < kKeep ? 64u : 0u) + (i - sh.s_tail[wave_id][lo]));
+        };
         for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
         __syncthreads();
         const bool own_inv = inv_L >= 0 && inv_part == p;
@@ -569,40 +562,45 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
 
         // phase a
         if (RUNS) {
-            // the first kKeep records of every thread stay in registers for phase b
+            {
+                // row 0 of block wave_id + 16 u: one scalar base per u, one lane offset for all
+                const unsigned lane_off = ((unsigned)wave_id << 6) | (unsigned)lane_id;
+                const unsigned long long *hrow = v.rec_h + tbase;
+                const uint32_t *wrow = v.rec_w + tbase;
+                const uint32_t *srow = PACKED ? nullptr : v.rec_s + tbase;
 #pragma unroll
-            for (int u = 0; u < kKeep; ++u) {
-                const unsigned t = rec_beg + threadIdx.x + u * kWinnerThreads;
-                if (t < rec_end) keep[u] = load_rec<PACKED>(v, fbase, t);
+                for (int u = 0; u < kKeep; ++u) {
+                    const unsigned c = __builtin_amdgcn_readlane(cvec, u);
+                    if ((unsigned)lane_id < c) {   // the block's first 64 records
+                        keep[u].h = hrow[lane_off + (unsigned)(u * kWaves * 64)];
+                        keep[u].w = wrow[lane_off + (unsigned)(u * kWaves * 64)];
+                        if constexpr (!PACKED) keep[u].s = srow[lane_off + (unsigned)(u * kWaves * 64)];
+                    }
+                }
             }
+            if ((unsigned)lane_id < tail_total) tail0 = load_rec<PACKED>(v, tbase + tail_offset(lane_id));
 #pragma unroll
             for (int u = 0; u < kKeep; ++u)
-                if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end)
+                if ((unsigned)lane_id < (unsigned)__builtin_amdgcn_readlane(cvec, u))
                     atomicMax(&table_h[keep[u].slot()], keep[u].h);
-            for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
-                Rec<PACKED> rec[kRunBatch];
-#pragma unroll
-                for (int u = 0; u < kRunBatch; ++u) {
-                    const unsigned t = t0 + u * kWinnerThreads;
-                    if (t < rec_end) rec[u] = load_rec<PACKED>(v, fbase, t);
-                }
-#pragma unroll
-                for (int u = 0; u < kRunBatch; ++u)
-                    if (t0 + u * kWinnerThreads < rec_end)
-                        atomicMax(&table_h[rec[u].slot()], rec[u].h);
+            if ((unsigned)lane_id < tail_total) atomicMax(&table_h[tail0.slot()], tail0.h);
+            for (unsigned i = 64u + lane_id; i < tail_total; i += 64u) {
+                const Rec<PACKED> rec = load_rec<PACKED>(v, tbase + tail_offset(i));
+                atomicMax(&table_h[rec.slot()], rec.h);
             }
         } else {
+        // scanned frame: the geometry is computed again for every table pass (rare, and exact
+        // by construction: the same function, the same inputs)
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
-            const uint4 id4 = ids4[q];
-            const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
-#pragma unroll
+            const float4 d4 = depth4[q];
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            const int r = (4 * q) / v.W, c0 = 4 * q - r * v.W;
+            const double yr = (double)r - (double)v.H / 2.0;
             for (int k = 0; k < 4; ++k) {
-                const uint32_t id = ids[k];
-                if (id == kDeadCell) continue;
-                const int rr = (int)((id >> kCoordBits) & kCoordMask) - rmin_b;
-                const int cc = (int)(id & kCoordMask) - cmin_b;
-                const int L = rr * bw + cc;
-                if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], hk[4 * q + k]);
+                const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
+                if (g.id == kDeadCell) continue;
+                const int L = (g.row - rmin) * bw + (g.col - cmin);
+                if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], g.key);
             }
         }
         }
@@ -616,36 +614,28 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
         if (RUNS) {
 #pragma unroll
             for (int u = 0; u < kKeep; ++u)
-                if (rec_beg + threadIdx.x + u * kWinnerThreads < rec_end &&
+                if ((unsigned)lane_id < (unsigned)__builtin_amdgcn_readlane(cvec, u) &&
                     table_h[keep[u].slot()] == keep[u].h)
                     atomicMin(&table_i[keep[u].slot()], keep[u].word());
-            for (unsigned t0 = rec_beg + kKeep * kWinnerThreads + threadIdx.x; t0 < rec_end; t0 += kWinnerThreads * kRunBatch) {
-                Rec<PACKED> rec[kRunBatch];
-#pragma unroll
-                for (int u = 0; u < kRunBatch; ++u) {
-                    const unsigned t = t0 + u * kWinnerThreads;
-                    if (t < rec_end) rec[u] = load_rec<PACKED>(v, fbase, t);
-                }
-#pragma unroll
-                for (int u = 0; u < kRunBatch; ++u)
-                    if (t0 + u * kWinnerThreads < rec_end &&
-                        table_h[rec[u].slot()] == rec[u].h)
-                        atomicMin(&table_i[rec[u].slot()], rec[u].word());
+            if ((unsigned)lane_id < tail_total && table_h[tail0.slot()] == tail0.h)
+                atomicMin(&table_i[tail0.slot()], tail0.word());
+            for (unsigned i = 64u + lane_id; i < tail_total; i += 64u) {
+                const Rec<PACKED> rec = load_rec<PACKED>(v, tbase + tail_offset(i));
+                if (table_h[rec.slot()] == rec.h) atomicMin(&table_i[rec.slot()], rec.word());
             }
         } else {
         for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
-            const uint4 id4 = ids4[q];
-            const uint32_t ids[4] = {id4.x, id4.y, id4.z, id4.w};
-#pragma unroll
+            const float4 d4 = depth4[q];
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            const int r = (4 * q) / v.W, c0 = 4 * q - r * v.W;
+            const double yr = (double)r - (double)v.H / 2.0;
             for (int k = 0; k < 4; ++k) {
-                const uint32_t id = ids[k];
-                if (id == kDeadCell) continue;
-                const int rr = (int)((id >> kCoordBits) & kCoordMask) - rmin_b;
-                const int cc = (int)(id & kCoordMask) - cmin_b;
-                const int L = rr * bw + cc;
+                const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
+                if (g.id == kDeadCell) continue;
+                const int L = (g.row - rmin) * bw + (g.col - cmin);
                 if ((L >> kSlotShift) == p) {
                     const int s = L & (kSlots - 1);
-                    if (hk[4 * q + k] == table_h[s])
+                    if (g.key == table_h[s])
                         atomicMin(&table_i[s], (unsigned)(4 * q + k) << 1);
                 }
             }
@@ -654,8 +644,8 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
         __syncthreads();
         // phase c: emit the surviving slots in slot order (= row-major cell order), so that
         // neighbouring list entries are neighbouring map cells
-        constexpr int kIters = kSlots / kWinnerThreads, kWaves = kWinnerThreads / 64;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        constexpr int kIters = kSlots / kWinnerThreads;
+        const int lane = lane_id, wave = wave_id;
         unsigned long long balls[kIters];
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
@@ -732,15 +722,20 @@ __device__ __forceinline__ void winners_body(const View &v, int write_target, in
     }
 }
 
-// Frames whose padded cell box fits the 16 tables are binned (k_header_scan, k_geometry_scatter) and
-// read as contiguous record ranges; larger boxes fall back to scanning every cell id once per table.
-__global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, int write_target, int write_list) {
+// Frames whose predicted cell box fits the 16 tables and holds every live pixel are read as
+// per-table record ranges; the others (spilled) are scanned pixel by pixel, once per table.
+__global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
+                                                            int write_target, int write_list) {
     __shared__ WinnerShared sh;
-    const FrameHeader *hdr = v.hdr + blockIdx.y;
-    if (hdr->rmin > hdr->rmax) return;
-    if (!bin_frame(hdr).on) winners_body<false, false>(v, write_target, write_list, sh);
-    else if (v.rec_packed) winners_body<true, true>(v, write_target, write_list, sh);
-    else winners_body<true, false>(v, write_target, write_list, sh);
+    FrameHeader *hdr = v.hdr + blockIdx.y;
+    fold_reports(v, blockIdx.y, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;
+        if (sh.frame.err) atomicOr(&hdr->status, sh.frame.err);
+    }
+    if (sh.frame.spill || !bin_frame(hdr).on || v.geom_blocks > kMaxGeomBlocksBinned) winners_body<false, false>(v, depth_all, write_target, write_list, sh);
+    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh);
+    else winners_body<true, false>(v, depth_all, write_target, write_list, sh);
 }
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
@@ -783,24 +778,24 @@ void launch_resolve_wrapped(const View &v, hipStream_t s) {
 
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
+    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
+    const int wt = prob_rule ? 1 : 0;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
     PosePack pack;
     if (host_poses) {   // at most kPosePack envs
         memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);
-        hipLaunchKernelGGL(k_geometry_count<true>, grid, dim3(256), 0, s, v, f.depth, pack);
+        if (v.rec_packed) hipLaunchKernelGGL((k_geometry<true, true>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
+        else hipLaunchKernelGGL((k_geometry<true, false>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
     } else {
-        hipLaunchKernelGGL(k_geometry_count<false>, grid, dim3(256), 0, s, v, f.depth, pack);
+        if (v.rec_packed) hipLaunchKernelGGL((k_geometry<false, true>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
+        else hipLaunchKernelGGL((k_geometry<false, false>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
     }
-    hipLaunchKernelGGL(k_header_scan, dim3(v.E), dim3(1024), 0, s, v, (int)grid.x);
 }
 
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    dim3 grid_geo((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
-    if (v.rec_packed) hipLaunchKernelGGL(k_geometry_scatter<true>, grid_geo, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
-    else hipLaunchKernelGGL(k_geometry_scatter<false>, grid_geo, dim3(256), 0, s, v, f.depth, prob_rule ? 1 : 0);
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, prob_rule ? 1 : 0, 1);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, prob_rule ? 1 : 0, 1);
 }
 
 }  // namespace ssmap

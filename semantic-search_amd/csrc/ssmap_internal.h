@@ -36,6 +36,9 @@ struct PoseBlock {
     int32_t robot_row, robot_col;   // world2map(agent position)
     int32_t goal_id;      // schema id of the goal
     int32_t pad;
+    // cell box {rmin, rmax, cmin, cmax} predicted to hold every live pixel of the frame: the camera
+    // frustum up to depth_max, padded, cut to the indexable range [-dim, dim).  rmin > rmax: none.
+    int32_t box[4];
 };
 
 // Engines of at most kPosePack envs hand the poses to the geometry kernel as a kernel argument
@@ -48,7 +51,7 @@ struct PosePack {
 
 // Per-env scratch header, rewritten every step.
 struct FrameHeader {
-    int32_t rmin, rmax, cmin, cmax;       // bbox of all live pixels' cells (unwrapped)
+    int32_t rmin, rmax, cmin, cmax;       // predicted box of the live pixels' cells (unwrapped)
     int32_t wrmin, wrmax, wcmin, wcmax;   // bbox of the update cells (unwrapped)
     uint32_t min_invalid_pixel;           // lowest flat index with depth <= 0
     uint32_t n_winners;
@@ -58,6 +61,16 @@ struct FrameHeader {
     uint32_t n_overlay;                   // hv: goal overlays written this step
     uint32_t n_neg;                       // update cells reached through a negative (wrapped) index
     uint32_t pad;
+};
+
+// What a geometry block reports about its pixels besides the records; the winner kernel folds
+// the blocks' reports of a frame.
+struct GeomPart {
+    uint32_t min_invalid_pixel;           // lowest flat index with depth <= 0, or kNoPixel
+    uint32_t err;                         // SSMAP_ENV_* bits
+    uint32_t spill;                       // some live pixel of the block is not in the tables
+    uint32_t pad;
+    int32_t rmin, rmax, cmin, cmax;       // box of the cells of the spilled pixels
 };
 
 struct EnvState {
@@ -76,17 +89,17 @@ struct View {
     const EnvState *envs;
     PoseBlock *poses;          // [E] written by the geometry kernel, read by the later kernels
     FrameHeader *hdr;
-    uint32_t *cellid;          // [E][N]
-    unsigned long long *horder;// [E][N] order-preserving image of the f64 height
-    int32_t *geo_part;         // [E][N/1024][8] per-geometry-block bbox / invalid pixel / error partials
-    // binned pixel records, one array per field, contiguous per winner table (k_bin_*):
-    unsigned long long *rec_h; // [E][N] height image
-    uint32_t *rec_w;           // [E][N] slot << kPackPixBits | pixel when the frame has at most
+    // Binned pixel records, one array per field.  Geometry block b owns kGeomPixPerBlock record
+    // places in every winner table (all its pixels may fall into one table) and reports how many
+    // it used: no block waits for another, and nothing has to be reset between steps.
+    int32_t geom_blocks;       // geometry blocks per frame = ceil(N / kGeomPixPerBlock)
+    GeomPart *geo_part;        // [E][geom_blocks]
+    unsigned int *bin_cnt;     // [E][kMaxParts][geom_blocks] records of block b in table t
+    unsigned long long *rec_h; // [E][kMaxParts][geom_blocks][kGeomPixPerBlock] height image
+    uint32_t *rec_w;           // same shape: slot << kPackPixBits | pixel when the frame has at most
                                //        2^kPackPixBits pixels (rec_packed), else the pixel
-    uint32_t *rec_s;           // [E][N] slot (only when !rec_packed)
+    uint32_t *rec_s;           // same shape: slot (only when !rec_packed)
     int32_t rec_packed;
-    unsigned int *bin_cnt;     // [E][N/1024][kMaxParts] per-block table counts, then record bases
-    unsigned int *part_start;  // [E][kMaxParts+1] first record of each table
     int32_t *target;           // [E][N] slot in the frame's update list, valid where wflag is set
     uint8_t *wflag;            // [E][N] 1 = this pixel owns a map cell this step (cleared by the geometry kernel)
     float *wprob;              // [E][N][wprob_stride] class probabilities of the update pixels, row = list slot

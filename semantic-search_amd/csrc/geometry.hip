@@ -382,40 +382,62 @@ struct WinnerShared {
     unsigned int s_tail[kWinnerThreads / 64][64];   // per wave: tail records in front of each of its blocks
 };
 
-// Folds the reports of the frame's geometry blocks (every winner block does it for itself).
-__device__ inline void fold_reports(const View &v, int e, WinnerShared &sh) {
-    unsigned min_inv = kNoPixel, flags = 0;
-    int rmin = 0x7FFFFFFF, rmax = (int)0x80000000, cmin = 0x7FFFFFFF, cmax = (int)0x80000000;
+// Folds the reports of the frame's geometry blocks (every winner block does it for itself).  The
+// loads are a step of their own so that the kernel can issue them together with its other
+// first loads, ahead of the barriers of the reduction.
+struct ReportRegs {
+    unsigned min_inv, flags;
+    int rmin, rmax, cmin, cmax;
+};
+__device__ inline ReportRegs load_reports(const View &v, int e) {
+    ReportRegs r;
+    r.min_inv = kNoPixel; r.flags = 0;
+    r.rmin = r.cmin = 0x7FFFFFFF;
+    r.rmax = r.cmax = (int)0x80000000;
     for (int b = threadIdx.x; b < v.geom_blocks; b += kWinnerThreads) {
         const uint4 *q = reinterpret_cast<const uint4 *>(v.geo_part + (int64_t)e * v.geom_blocks + b);
         const uint4 a = q[0], c = q[1];
-        min_inv = min(min_inv, a.x);
-        flags |= a.y | (a.z ? 0x80000000u : 0u);
-        rmin = min(rmin, (int)c.x); rmax = max(rmax, (int)c.y);
-        cmin = min(cmin, (int)c.z); cmax = max(cmax, (int)c.w);
+        r.min_inv = min(r.min_inv, a.x);
+        r.flags |= a.y | (a.z ? 0x80000000u : 0u);
+        r.rmin = min(r.rmin, (int)c.x); r.rmax = max(r.rmax, (int)c.y);
+        r.cmin = min(r.cmin, (int)c.z); r.cmax = max(r.cmax, (int)c.w);
     }
+    return r;
+}
+__device__ inline void fold_reports(ReportRegs r, WinnerShared &sh) {
     if (threadIdx.x == 0) {
         sh.frame.min_invalid_pixel = kNoPixel; sh.frame.err = 0; sh.frame.spill = 0; sh.frame.pad = 0;
         sh.frame.rmin = sh.frame.cmin = 0x7FFFFFFF;
         sh.frame.rmax = sh.frame.cmax = (int)0x80000000;
     }
     __syncthreads();
-    min_inv = wave_min_u32(min_inv);
-    rmin = wave_min(rmin); rmax = wave_max(rmax);
-    cmin = wave_min(cmin); cmax = wave_max(cmax);
+    const unsigned min_inv = wave_min_u32(r.min_inv);
+    unsigned flags = r.flags;
     const bool any_flag = __ballot(flags != 0) != 0ull;
-    for (int o = 32; o > 0 && any_flag; o >>= 1) flags |= (unsigned)__shfl_xor((int)flags, o);
-    if ((threadIdx.x & 63) == 0) {
-        if (min_inv != kNoPixel) atomicMin(&sh.frame.min_invalid_pixel, min_inv);
-        if (flags & 0x7FFFFFFFu) atomicOr(&sh.frame.err, flags & 0x7FFFFFFFu);
-        if (flags & 0x80000000u) sh.frame.spill = 1u;
-        if (rmin <= rmax) {
-            atomicMin(&sh.frame.rmin, rmin); atomicMax(&sh.frame.rmax, rmax);
-            atomicMin(&sh.frame.cmin, cmin); atomicMax(&sh.frame.cmax, cmax);
+    if ((threadIdx.x & 63) == 0 && min_inv != kNoPixel) atomicMin(&sh.frame.min_invalid_pixel, min_inv);
+    if (any_flag) {   // rare: index errors or spilled pixels
+        for (int o = 32; o > 0; o >>= 1) flags |= (unsigned)__shfl_xor((int)flags, o);
+        const int rmin = wave_min(r.rmin), rmax = wave_max(r.rmax), cmin = wave_min(r.cmin), cmax = wave_max(r.cmax);
+        if ((threadIdx.x & 63) == 0) {
+            if (flags & 0x7FFFFFFFu) atomicOr(&sh.frame.err, flags & 0x7FFFFFFFu);
+            if (flags & 0x80000000u) sh.frame.spill = 1u;
+            if (rmin <= rmax) {
+                atomicMin(&sh.frame.rmin, rmin); atomicMax(&sh.frame.rmax, rmax);
+                atomicMin(&sh.frame.cmin, cmin); atomicMax(&sh.frame.cmax, cmax);
+            }
         }
     }
     __syncthreads();
 }
+
+// What a winner block reads about its frame before anything else, issued as one group of loads.
+struct WinnerPre {
+    int rmin, rmax, cmin, cmax;      // predicted box (frame header)
+    int Hm, Wm;
+    double lower_x, lower_z;
+    double cam_x, cam_y, cam_z, h_cut;
+    unsigned cnt;                    // bin_cnt of geometry block wave + 16 lane for table blockIdx.x
+};
 
 // One binned record in registers.  The not-updatable flag is not stored: a pixel in a table has
 // valid depth and lies inside the upper bounds, so it is updatable exactly when its height is
@@ -456,7 +478,7 @@ __device__ inline Rec<false> load_rec<false>(const View &v, int64_t at) {
 
 template <bool RUNS, bool PACKED>
 __device__ __forceinline__ void winners_body(const View &v, const float *__restrict__ depth_all, int write_target,
-                                             int write_list, WinnerShared &sh) {
+                                             int write_list, WinnerShared &sh, const WinnerPre &pre) {
     unsigned long long (&table_h)[kSlots] = sh.table_h;
     unsigned int (&table_i)[kSlots] = sh.table_i;
     unsigned int &s_base = sh.s_base, &s_neg = sh.s_neg;
@@ -467,7 +489,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     const int64_t fbase = (int64_t)e * v.N;
     FrameHeader *hdr = v.hdr + e;
     const GeomPart *acc = &sh.frame;
-    int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
+    int rmin = pre.rmin, rmax = pre.rmax, cmin = pre.cmin, cmax = pre.cmax;
     if (!RUNS) {
         // scanned frame: the cells lie in the box of the spilled pixels, joined with the predicted
         // box when that one was in use (its pixels were not accumulated)
@@ -479,7 +501,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     if (rmin > rmax || cmin > cmax) return;
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
-    const int Hm = mp.map_h, Wm = mp.map_w;
+    const int Hm = pre.Hm, Wm = pre.Wm;
     const int bw = cmax - cmin + 1;
     const long long ncell = (long long)bw * (long long)(rmax - rmin + 1);
     const int nfull = (int)((ncell + kSlots - 1) >> kSlotShift);
@@ -492,13 +514,13 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     long long inv_L = -1;
     unsigned long long inv_key = 0;
     if (min_inv != kNoPixel) {
-        const double fr = floor(((0.0 + pb.trans[2]) - mp.lower[2]) / v.p2m);
-        const double fc = floor(((0.0 + pb.trans[0]) - mp.lower[0]) / v.p2m);
+        const double fr = floor(((0.0 + pre.cam_z) - pre.lower_z) / v.p2m);
+        const double fc = floor(((0.0 + pre.cam_x) - pre.lower_x) / v.p2m);
         if (fabs(fr) < 1.0e9 && fabs(fc) < 1.0e9) {
             const int row = (int)fr, col = (int)fc;
             if (row >= rmin && row <= rmax && col >= cmin && col <= cmax) {
                 inv_L = (long long)(row - rmin) * bw + (col - cmin);
-                inv_key = order_f64(0.0 + pb.trans[1]);
+                inv_key = order_f64(0.0 + pre.cam_y);
             }
         }
     }
@@ -535,7 +557,8 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         if (RUNS) {
             const unsigned int *cnt = v.bin_cnt + ((int64_t)e * kBinParts + p) * nb;
             const int b = wave_id + kWaves * lane_id;
-            cvec = b < nb ? min(cnt[b], (unsigned)kGeomPixPerBlock) : 0u;
+            const unsigned raw = p == (int)blockIdx.x ? pre.cnt : (b < nb ? cnt[b] : 0u);   // first table: loaded up front
+            cvec = min(raw, (unsigned)kGeomPixPerBlock);
             const unsigned tn = lane_id < kKeep ? (cvec > 64u ? cvec - 64u : 0u) : cvec;
             unsigned incl = tn;
             for (int o = 1; o < 64; o <<= 1) {
@@ -652,14 +675,22 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             const unsigned w = table_i[it * kWinnerThreads + threadIdx.x];
             // updatable: not the invalid-depth entry, and below the height cut-off
             balls[it] = __ballot(w != kNoPixel && !(w & 1u) &&
-                                 unorder_f64(table_h[it * kWinnerThreads + threadIdx.x]) < pb.h_cut);
+                                 unorder_f64(table_h[it * kWinnerThreads + threadIdx.x]) < pre.h_cut);
             if (lane == 0) s_cnt[it * kWaves + wave] = (unsigned)__popcll(balls[it]);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned run = 0;
-            for (int k = 0; k < kIters * kWaves; ++k) { const unsigned c = s_cnt[k]; s_cnt[k] = run; run += c; }
-            s_base = run ? atomicAdd(&hdr->n_winners, run) : 0u;
+        // exclusive prefix sums of the kIters * kWaves ballot counts, by the first wave
+        static_assert(kIters * kWaves == 128, "two counts per lane");
+        if (wave == 0) {
+            const unsigned c0 = s_cnt[2 * lane], c1 = s_cnt[2 * lane + 1];
+            unsigned incl = c0 + c1;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            s_cnt[2 * lane] = incl - c0 - c1;
+            s_cnt[2 * lane + 1] = incl - c1;
+            if (lane == 63) s_base = incl ? atomicAdd(&hdr->n_winners, incl) : 0u;
         }
         __syncthreads();
         unsigned n_neg = 0;
@@ -727,15 +758,33 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
                                                             int write_target, int write_list) {
     __shared__ WinnerShared sh;
-    FrameHeader *hdr = v.hdr + blockIdx.y;
-    fold_reports(v, blockIdx.y, sh);
+    const int e = blockIdx.y;
+    FrameHeader *hdr = v.hdr + e;
+    // every first load of the block in one group: the latencies overlap instead of adding up
+    const ReportRegs rep = load_reports(v, e);
+    WinnerPre pre;
+    {
+        const ssmap_env_maps &mp = v.envs[e].maps;
+        const PoseBlock &pb = v.poses[e];
+        pre.rmin = hdr->rmin; pre.rmax = hdr->rmax; pre.cmin = hdr->cmin; pre.cmax = hdr->cmax;
+        pre.Hm = mp.map_h; pre.Wm = mp.map_w;
+        pre.lower_x = mp.lower[0]; pre.lower_z = mp.lower[2];
+        pre.cam_x = pb.trans[0]; pre.cam_y = pb.trans[1]; pre.cam_z = pb.trans[2];
+        pre.h_cut = pb.h_cut;
+        const int b = (int)(threadIdx.x >> 6) + (kWinnerThreads / 64) * (int)(threadIdx.x & 63);
+        pre.cnt = (v.geom_blocks <= kMaxGeomBlocksBinned && b < v.geom_blocks)
+                      ? v.bin_cnt[((int64_t)e * kMaxParts + blockIdx.x) * v.geom_blocks + b] : 0u;
+    }
+    fold_reports(rep, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;
         if (sh.frame.err) atomicOr(&hdr->status, sh.frame.err);
     }
-    if (sh.frame.spill || !bin_frame(hdr).on || v.geom_blocks > kMaxGeomBlocksBinned) winners_body<false, false>(v, depth_all, write_target, write_list, sh);
-    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh);
-    else winners_body<true, false>(v, depth_all, write_target, write_list, sh);
+    const int32_t box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
+    if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)
+        winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre);
+    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre);
+    else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre);
 }
 
 // numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which

@@ -544,7 +544,10 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     int lrmin = 0x7FFFFFFF, lrmax = (int)0x80000000, lcmin = 0x7FFFFFFF, lcmax = (int)0x80000000;
     if (threadIdx.x == 0) s_neg = 0;
 
-    for (int p = blockIdx.x; p < nparts; p += gridDim.x) {
+    // binned frames: one table per block, a single trip (the launch has kBinParts blocks per env);
+    // scanned frames may have more tables than blocks
+    static_assert(kWinnerPartsPerEnv == kBinParts, "one block per table on the binned path");
+    for (int p = blockIdx.x; p < nparts; p += RUNS ? kBinParts : (int)gridDim.x) {
         // Binned records of this table: geometry block b left bin_cnt[b] of them in its share, in
         // rows of 64.  Wave w takes the blocks w, w + 16, ...; lane l keeps the books of the l-th
         // of them.  Row 0 of the wave's first kKeep blocks is read one lane per record and stays in
@@ -577,7 +580,8 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             }
             return rec_offset(v, wave_id + kWaves * lo, (lo < kKeep ? 64u : 0u) + (i - sh.s_tail[wave_id][lo]));
         };
-        for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
+        // (the tables are clear here: the kernel clears them first thing, and an iteration that
+        // is followed by another clears them again at its end)
         __syncthreads();
         const bool own_inv = inv_L >= 0 && inv_part == p;
         if (own_inv && threadIdx.x == 0) table_h[inv_slot] = inv_key;
@@ -728,6 +732,8 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
         if (n_neg) atomicAdd(&s_neg, n_neg);
         __syncthreads();
+        if (!RUNS && p + (int)gridDim.x < nparts)
+            for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
     }
 
     // bbox of the update cells (goal_decay works on it, mapper.py:1117-1118)
@@ -775,6 +781,8 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         pre.cnt = (v.geom_blocks <= kMaxGeomBlocksBinned && b < v.geom_blocks)
                       ? v.bin_cnt[((int64_t)e * kMaxParts + blockIdx.x) * v.geom_blocks + b] : 0u;
     }
+    // clearing the tables overlaps with those loads
+    for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { sh.table_h[s] = 0ull; sh.table_i[s] = kNoPixel; }
     fold_reports(rep, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;

@@ -157,8 +157,8 @@ def test_frame_above_packed_record_limit():
 
 
 def test_far_depths_take_the_unbinned_winner_path():
-    """Depths up to 30 m on a 960 x 960 map: the frame's cell box is far larger than the winner
-    tables hold, so the engine writes cell ids per pixel and every table block scans them."""
+    """Depths up to 30 m on a 960 x 960 map with depth_range up to 40 m: the predicted cell box is
+    far larger than the winner tables hold, so every table block scans the pixels instead."""
     import semantic_search_amd as ssa
     h, w, c = 120, 160, 8
     lut = scenes.small_lut(c)
@@ -191,6 +191,73 @@ def test_far_depths_take_the_unbinned_winner_path():
     _close(maps["avg_prob_seg_map"].cpu().numpy(), ref.avg_prob_seg_map, "avg_prob_seg_map")
     assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
     assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+    eng.close()
+
+
+def _drive(eng, ref, maps, frames_poses, h, w):
+    for i, (frame, agent, cam) in enumerate(frames_poses):
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs["depth"] = frame["depth"].copy()
+        ref.update(obs)
+        eng.step(_to_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 probs=_to_dev(frame["semantic_prob"][None], np.float32),
+                 semantic_gt=_to_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        assert status[0] == 0
+        pix, _ = eng.update_list(0, int(n_upd[0]))
+        assert np.array_equal(np.sort(pix), np.sort(ref.last_update_pixels)), f"frame {i}: update set"
+    _close(maps["avg_prob_seg_map"].cpu().numpy(), ref.avg_prob_seg_map, "avg_prob_seg_map")
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+
+
+def test_depths_beyond_depth_max_leave_the_predicted_box():
+    """depth_range (0.5, 5.0) but a few pixels at 6 to 9 m (only the exact maximum is a sentinel,
+    mapper.py:279-283): their cells lie outside the cell box the host predicts from the view
+    pyramid up to depth_max, so the frame takes the scanning winner path.  The second frame stays
+    inside the range and is binned again."""
+    import semantic_search_amd as ssa
+    h, w, c = 120, 160, 8
+    lut = scenes.small_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
+    eng.set_schema(lut)
+    ref.reset(BOUNDS_480)
+    maps = eng.reset_env(0, BOUNDS_480)
+    rng, prng = np.random.default_rng(31), np.random.default_rng(32)
+    seq = []
+    for i in range(2):
+        frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
+        if i == 0:
+            far = rng.random((h, w)) < 0.01
+            frame["depth"] = np.where(far, rng.uniform(6.0, 9.0, (h, w)).astype(np.float32), frame["depth"])
+        agent, cam = scenes.make_pose(7.2, 0.0, 7.2, prng.uniform(0, 2 * np.pi))
+        seq.append((frame, agent, cam))
+    _drive(eng, ref, maps, seq, h, w)
+    far_rows = np.nonzero(np.isfinite(ref.height_map).any(axis=1))[0]
+    assert far_rows.max() - far_rows.min() > 2 * int(5.0 / 0.03) * 0.6, "some cells must lie beyond the 5 m reach"
+    eng.close()
+
+
+def test_frame_of_more_than_a_million_pixels():
+    """1056 x 1024 pixels = 1056 geometry blocks, more than a winner block keeps books for: the
+    frame takes the scanning winner path whatever its cell box."""
+    import semantic_search_amd as ssa
+    h, w, c = 1056, 1024, 5
+    lut = scenes.small_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
+    eng.set_schema(lut)
+    ref.reset(BOUNDS_480)
+    maps = eng.reset_env(0, BOUNDS_480)
+    rng, prng = np.random.default_rng(41), np.random.default_rng(42)
+    frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
+    agent, cam = scenes.make_pose(7.2, 0.0, 7.2, prng.uniform(0, 2 * np.pi))
+    _drive(eng, ref, maps, [(frame, agent, cam)], h, w)
     eng.close()
 
 

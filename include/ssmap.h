@@ -163,8 +163,8 @@ int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev);
 
 /* Measurement hooks (no counterpart in the reference).  After ssmap_profile_begin the next
  * `max_steps` calls of ssmap_step record HIP events on their stream around five stage
- * groups: [0] geometry count pass + frame header, [1] geometry scatter pass + tallest-per-cell
- * + wrap resolution,
+ * groups: [0] geometry pass (pixel records + frame header), [1] tallest-per-cell + wrap
+ * resolution,
  * [2] the streaming stage-1 kernel (one launch), [3] rule update, [4] found decision.
  * ssmap_profile_read waits for `stream`, returns the summed milliseconds per group
  * (stage_ms[5]) and the number of recorded steps, and rearms. */

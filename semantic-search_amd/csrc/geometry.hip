@@ -1,6 +1,6 @@
 // Stages 2 and 3 of the fusion path for gfx950:
-//   k_geometry_count / k_geometry_scatter   depth -> world point -> map cell + height, run twice
-//                 over the depth image (count per winner table, then scatter into the tables)
+//   k_geometry    depth -> world point -> map cell + height, one pass over the depth image that
+//                 leaves one record per live pixel in the winner table of its cell
 //                 (mapper.py:279-283 sentinels, :18-32 pointcloud, :305-311 rotate/translate,
 //                  :851-863 world2map, :319-329 masks)
 //   k_winners     tallest point per cell, ties -> lowest pixel index (mapper.py:331), then

@@ -49,7 +49,9 @@ typedef enum ssmap_rule {
     SSMAP_RULE_W2_AVG_PROB = 5,  /* w2_avg_prob  (weight 1 / entropy)   mapper.py:533-537 */
     SSMAP_RULE_LOG_ODDS = 6,     /* log_odds                            mapper.py:570-603 */
     SSMAP_RULE_HV = 7,           /* height_map_hv                       mapper.py:604-666 */
-    SSMAP_RULE_PROB_HV = 8       /* height_map_prob_hv                  mapper.py:667-727 */
+    SSMAP_RULE_PROB_HV = 8,      /* height_map_prob_hv                  mapper.py:667-727 */
+    SSMAP_RULE_STUBBORN = 9      /* stubborn: argmax + per-cell goal statistics + a Gaussian
+                                    naive-Bayes veto of goal labels      mapper.py:412-515 */
 } ssmap_rule;
 
 /* Per-env status bits reported by ssmap_read_results(). */
@@ -93,6 +95,11 @@ typedef struct ssmap_env_maps {
     uint32_t *background_map;
     float    *hits;
     float    *views;
+    /* stubborn rule / collect_nb_data (mapper.py:244-250, 260-264) */
+    uint32_t *total_view;
+    float    *cumulative_conf;
+    float    *max_conf;
+    float    *max_other_conf;
 } ssmap_env_maps;
 
 /* Attributes the reference's callers overwrite after construction
@@ -105,6 +112,9 @@ typedef struct ssmap_params {
     float   hv_ratio, hv_min_views;
     double  hv_limit_obj_view_dist;
     double  found_dist_m;        /* radius of the found disk = int(found_dist_m / pixel2meter) */
+    int32_t nb_stats;            /* collect_nb_data with the argmax rule: keep the four goal
+                                    statistics of mapper.py:448-469 (always kept by stubborn) */
+    int32_t pad;
 } ssmap_params;
 
 /* One batch of frames (one per env) = the `obs` dicts of E update_map calls
@@ -135,6 +145,19 @@ int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n,
 /* color_pallete (mapper.py:102-105): n rows of RGB. */
 int ssmap_set_palette(ssmap_engine *eng, const uint8_t *rgb, int32_t n);
 int ssmap_set_params(ssmap_engine *eng, const ssmap_params *p);
+
+/* One Gaussian naive-Bayes model of the stubborn rule (mapper.py:184-191 loads them from a
+ * pickle; here the caller passes the fitted arrays): the model for schema goal id `goal_sem_id`
+ * (3..8) over the features {total_view, cumulative_conf, max_conf, max_other_conf}
+ * (mapper.py:502-510).  n_classes is 1 or 2; classes[k] is the label of row k (sklearn's
+ * classes_), class_log_prior[k] = log(class_prior_[k]), norm_const[k] =
+ * -0.5 * sum_j log(2 pi var_[k][j]), theta / var are [n_classes][4] row-major (theta_, var_).
+ * The engine evaluates log prior + (norm_const - 0.5 * sum_j (x_j - theta)^2 / var) in float64
+ * and takes the first largest.  A goal cell predicted as label 0 is stored as id 2
+ * (mapper.py:512-515). */
+int ssmap_set_nb_model(ssmap_engine *eng, int32_t goal_sem_id, int32_t n_classes,
+                       const int32_t *classes, const double *class_log_prior,
+                       const double *norm_const, const double *theta, const double *var);
 
 /* SemanticMapper.reset (mapper.py:193-269) for env `e`: binds freshly initialised maps. */
 int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps);

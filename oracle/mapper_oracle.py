@@ -10,8 +10,8 @@ float64 per-pixel geometry.  Pinning: tests/test_oracle_golden.py checks this mo
 against tests/golden/*.npz, which were recorded from the reference's own mapper.py (see
 tests/golden/make_golden.py for how, and for which third-party seams are unpinned).
 
-Not restated (outside the fusion path): ego-map rendering (mapper.py:876-998), the path
-overlay (mapper.py:822-833), the "stubborn" rule and NB-data collection (mapper.py:448-515).
+Not restated here: ego-map rendering (mapper.py:876-998; see egomap_oracle.py) and the path
+overlay (mapper.py:822-833).
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle_geometry.so")
 _lib = None
 
 AVG_RULES = ("avg_prob", "w_avg_prob", "w2_avg_prob")
-KNOWN_RULES = AVG_RULES + ("log_odds", "goal_decay", "argmax", "hv", "prob_hv")
+KNOWN_RULES = AVG_RULES + ("log_odds", "goal_decay", "argmax", "hv", "prob_hv", "stubborn")
 
 
 def build_geometry_lib(force: bool = False) -> str:
@@ -174,7 +174,7 @@ class OracleMapper:
                  pixel2meter=0.03, height_cutoff_m=0.1, entropy_threshold=0.5,
                  probablistic_mapping=False, prob_aggregate="height_map_argmax",
                  success_dist_m=1.0, seg_model_n_classes=None, filter_goal_prob=None,
-                 schema_lut=None):
+                 schema_lut=None, collect_nb_data=False, nb_models=None, objnav_to_sem_pred=None):
         self.num_semantic_classes = num_semantic_classes
         self.depth_hfov = depth_hfov
         self.depth_range = depth_range
@@ -186,6 +186,9 @@ class OracleMapper:
         self.sem_model_n_classes = seg_model_n_classes
         self.filter_goal_prob = filter_goal_prob
         self.schema_lut = None if schema_lut is None else np.asarray(schema_lut)
+        self.collect_nb_data = collect_nb_data
+        self.nb_models = nb_models                    # {goal id: dict(classes_, class_prior_, theta_, var_)}
+        self.objnav_to_sem_pred = objnav_to_sem_pred  # {goal id: model classes of that goal}
         self.use_height = prob_aggregate.startswith("height_map_")
         self.rule = prob_aggregate[len("height_map_"):] if self.use_height else prob_aggregate
         if self.rule not in KNOWN_RULES:
@@ -214,6 +217,13 @@ class OracleMapper:
         self.semantic_map_color = np.zeros((nr, nc, 3), np.uint8)
         self.height_map = np.full((nr, nc), -np.inf, f32)
         self.unc_map = None
+        if self.collect_nb_data or (self.probablistic_mapping and self.rule == "stubborn"):
+            # mapper.py:244-250, 260-265
+            self.total_view = np.zeros((nr, nc), u32)
+            self.cumulative_conf = np.zeros((nr, nc), f32)
+            self.max_conf = np.zeros((nr, nc), f32)
+            self.max_other_conf = np.zeros((nr, nc), f32)
+            self.eps_nb_data = {"goal": [], "non_goal": [], "goal_id": None}
         if not self.probablistic_mapping:
             self.gt_map = self.semantic_map
             return
@@ -296,7 +306,41 @@ class OracleMapper:
         if self.filter_goal_prob is not None:
             self._filter_goal(ids, 1 - obs["semantic_unc"].reshape(-1)[pix], goal_id)
         self._occupancy_override(ids, cells)
+        if self.collect_nb_data or self.rule == "stubborn":
+            self._goal_statistics(obs, pix, cells, ids, goal_id)
         return cells, ids
+
+    def _fuse_stubborn(self, obs, pix, cells, goal_id, agent, lower):
+        return self._fuse_argmax(obs, pix, cells, goal_id, agent, lower)
+
+    def _goal_statistics(self, obs, pix, cells, ids, goal_id):
+        """mapper.py:448-515: four running statistics per cell; collection of feature rows, or the
+        naive-Bayes veto of goal labels."""
+        self.total_view[cells] += 1
+        goal_classes = self.objnav_to_sem_pred[goal_id]
+        prob = obs["semantic_prob"].transpose(1, 2, 0)
+        n_classes = prob.shape[-1]
+        others = np.delete(np.arange(n_classes), goal_classes)
+        flat = prob.reshape(-1, n_classes)
+        goal_mass = np.sum(flat[:, goal_classes], axis=-1)
+        self.cumulative_conf[cells] += goal_mass[pix]
+        self.max_conf[cells] = np.maximum(self.max_conf[cells], goal_mass[pix])
+        other_max = np.max(flat[:, others], axis=-1)
+        self.max_other_conf[cells] = np.maximum(self.max_other_conf[cells], other_max[pix])
+        cols = [self.total_view[cells], self.cumulative_conf[cells], self.max_conf[cells],
+                self.max_other_conf[cells]]
+        if self.collect_nb_data:
+            is_goal = self.gt_map[cells] == goal_id
+            if is_goal.any():
+                self.eps_nb_data["goal"].append(np.stack([c[is_goal] for c in cols], axis=-1))
+            if not is_goal.any():
+                self.eps_nb_data["non_goal"].append(np.stack([c[~is_goal] for c in cols], axis=-1))
+            self.eps_nb_data["goal_id"] = goal_id
+        else:
+            features = np.stack(cols, axis=-1)
+            if len(features) > 0:
+                pred = gaussian_nb_predict(self.nb_models[goal_id], features)
+                ids[(pred == 0) & (ids == goal_id)] = 2
 
     def _fuse_goal_decay(self, obs, pix, cells, goal_id, agent, lower):
         ids = obs["semantic"].reshape(-1)[pix]
@@ -431,6 +475,23 @@ class OracleMapper:
             ent = scipy.stats.entropy(pr, axis=-1, base=c)
             return True if np.any(ent < self.entropy_threshold) else None
         return True if np.any(goal) else None
+
+
+def gaussian_nb_predict(model, features):
+    """sklearn GaussianNB.predict restated (naive_bayes.py, _joint_log_likelihood): per class
+    log prior - 0.5 sum log(2 pi var) - 0.5 sum (x - theta)^2 / var, label of the first largest."""
+    get = (lambda k: model[k]) if isinstance(model, dict) else (lambda k: getattr(model, k))
+    classes, prior = np.asarray(get("classes_")), np.asarray(get("class_prior_"), dtype=np.float64)
+    theta, var = np.asarray(get("theta_"), dtype=np.float64), np.asarray(get("var_"), dtype=np.float64)
+    x = np.asarray(features, dtype=np.float64)
+    jll = []
+    for i in range(classes.shape[0]):
+        jointi = np.log(prior[i])
+        n_ij = -0.5 * np.sum(np.log(2.0 * np.pi * var[i, :]))
+        n_ij = n_ij - 0.5 * np.sum(((x - theta[i, :]) ** 2) / (var[i, :]), 1)
+        jll.append(jointi + n_ij)
+    jll = np.array(jll).T
+    return classes[np.argmax(jll, axis=1)]
 
 
 def palette(n):

@@ -12,13 +12,13 @@ MAX_CLASSES = 256
 MAX_POOL = 8
 
 RULES = {"direct": 0, "argmax": 1, "goal_decay": 2, "avg_prob": 3, "w_avg_prob": 4,
-         "w2_avg_prob": 5, "log_odds": 6, "hv": 7, "prob_hv": 8}
+         "w2_avg_prob": 5, "log_odds": 6, "hv": 7, "prob_hv": 8, "stubborn": 9}
 ENV_INDEX_ERROR = 1
 
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
            "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_stage1",
            "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
-           "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_last_error", "ssmap_version")
+           "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_set_nb_model", "ssmap_last_error", "ssmap_version")
 
 
 class Config(C.Structure):
@@ -35,14 +35,17 @@ class EnvMaps(C.Structure):
                 ("semantic_map", C.c_void_p), ("semantic_map_color", C.c_void_p),
                 ("height_map", C.c_void_p), ("gt_map", C.c_void_p), ("unc_map", C.c_void_p),
                 ("prob_map", C.c_void_p), ("weight_map", C.c_void_p), ("goal_map", C.c_void_p),
-                ("background_map", C.c_void_p), ("hits", C.c_void_p), ("views", C.c_void_p)]
+                ("background_map", C.c_void_p), ("hits", C.c_void_p), ("views", C.c_void_p),
+                ("total_view", C.c_void_p), ("cumulative_conf", C.c_void_p), ("max_conf", C.c_void_p),
+                ("max_other_conf", C.c_void_p)]
 
 
 class Params(C.Structure):
     _fields_ = [("entropy_threshold", C.c_float), ("filter_goal_prob", C.c_float),
                 ("use_filter", C.c_int32), ("goal_decay", C.c_float), ("goal_mark", C.c_float),
                 ("hv_ratio", C.c_float), ("hv_min_views", C.c_float),
-                ("hv_limit_obj_view_dist", C.c_double), ("found_dist_m", C.c_double)]
+                ("hv_limit_obj_view_dist", C.c_double), ("found_dist_m", C.c_double),
+                ("nb_stats", C.c_int32), ("pad", C.c_int32)]
 
 
 class Frames(C.Structure):
@@ -92,6 +95,7 @@ def load():
     lib.ssmap_profile_read.argtypes = [vp, vp, vp, vp]
     lib.ssmap_set_egomap.argtypes = [vp, C.POINTER(EgomapConfig)]
     lib.ssmap_ego_maps.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ssmap_set_nb_model.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.ssmap_last_error.restype = C.c_char_p
     lib.ssmap_version.restype = C.c_char_p
     for name in EXPORTS:

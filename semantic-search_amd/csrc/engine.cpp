@@ -111,6 +111,9 @@ struct ssmap_engine {
     std::vector<FrameHeader> h_hdr;
     int32_t *d_lut = nullptr, *d_pool_ids = nullptr, *d_pool_count = nullptr, *d_disk = nullptr;
     uint8_t *d_palette = nullptr;
+    NbModel *d_nb = nullptr;               // [6] naive-Bayes models of the stubborn rule, by goal id - 3
+    bool nb_set[6] = {};
+    float *d_nb_probs = nullptr;           // [E][C][N] stage-1 probabilities when that rule is fed logits
     int palette_rows = 0;
     bool have_params = false, have_schema = false, have_palette = false;
     Quat flip_cam{};
@@ -164,6 +167,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
     hipFree(eng->d_disk); hipFree(eng->d_palette); hipFree(eng->d_ego);
+    hipFree(eng->d_nb); hipFree(eng->d_nb_probs);
     for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
     for (int i = 0; i < kPoseRing; ++i) {
         if (eng->h_ring[i]) hipHostFree(eng->h_ring[i]);
@@ -180,7 +184,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
         return fail(SSMAP_ERR_INVALID_ARG, "n_envs >= 1, img_h >= 1 and img_w a positive multiple of 4 are required");
     if ((int64_t)c.img_h * c.img_w >= (1 << 29))
         return fail(SSMAP_ERR_INVALID_ARG, "frame too large");
-    if (c.rule < SSMAP_RULE_DIRECT || c.rule > SSMAP_RULE_PROB_HV)
+    if (c.rule < SSMAP_RULE_DIRECT || c.rule > SSMAP_RULE_STUBBORN)
         return fail(SSMAP_ERR_INVALID_ARG, "Invalid prob_aggregate");
     const bool prob_rule = c.rule >= SSMAP_RULE_AVG_PROB && c.rule <= SSMAP_RULE_LOG_ODDS;
     // the class tensor lives in LDS as [C][257] floats next to 2 KiB of bookkeeping
@@ -250,6 +254,9 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
     TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
     TRY_ALLOC(dev_alloc(&eng->d_pool_count, (size_t)6));
+    TRY_ALLOC(dev_alloc(&eng->d_nb, (size_t)6));
+    hipMemset(eng->d_nb, 0, 6 * sizeof(NbModel));
+    v.nb = eng->d_nb;
     hipMemset(eng->d_pool_count, 0, 6 * sizeof(int32_t));
     hipMemset(eng->d_lut, 0, SSMAP_MAX_CLASSES * sizeof(int32_t));
 #undef TRY_ALLOC
@@ -305,6 +312,30 @@ int ssmap_set_palette(ssmap_engine *eng, const uint8_t *rgb, int32_t n) {
     return SSMAP_OK;
 }
 
+int ssmap_set_nb_model(ssmap_engine *eng, int32_t goal_sem_id, int32_t n_classes, const int32_t *classes,
+                       const double *class_log_prior, const double *norm_const, const double *theta,
+                       const double *var) {
+    if (!eng || !classes || !class_log_prior || !norm_const || !theta || !var)
+        return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    if (goal_sem_id < 3 || goal_sem_id > 8) return fail(SSMAP_ERR_INVALID_ARG, "goal_sem_id must be in [3, 8]");
+    if (n_classes < 1 || n_classes > 2) return fail(SSMAP_ERR_UNSUPPORTED, "naive-Bayes models of one or two classes");
+    NbModel m{};
+    m.n_classes = n_classes;
+    for (int k = 0; k < n_classes; ++k) {
+        m.classes[k] = classes[k];
+        m.log_prior[k] = class_log_prior[k];
+        m.konst[k] = norm_const[k];
+        for (int j = 0; j < 4; ++j) {
+            if (!(var[4 * k + j] > 0)) return fail(SSMAP_ERR_INVALID_ARG, "variances must be positive");
+            m.theta[k][j] = theta[4 * k + j];
+            m.var[k][j] = var[4 * k + j];
+        }
+    }
+    HIP_TRY(hipMemcpy(eng->d_nb + (goal_sem_id - 3), &m, sizeof(NbModel), hipMemcpyHostToDevice));
+    eng->nb_set[goal_sem_id - 3] = true;
+    return SSMAP_OK;
+}
+
 int ssmap_set_params(ssmap_engine *eng, const ssmap_params *p) {
     if (!eng || !p) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
     const int radius = (int)(p->found_dist_m / eng->cfg.pixel2meter);
@@ -343,6 +374,9 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
         return fail(SSMAP_ERR_INVALID_ARG, "goal_map is required for this rule");
     if ((r == SSMAP_RULE_HV || r == SSMAP_RULE_PROB_HV) && (!maps->background_map || !maps->hits || !maps->views))
         return fail(SSMAP_ERR_INVALID_ARG, "background_map, hits and views are required for this rule");
+    if (r == SSMAP_RULE_STUBBORN &&
+        (!maps->total_view || !maps->cumulative_conf || !maps->max_conf || !maps->max_other_conf))
+        return fail(SSMAP_ERR_INVALID_ARG, "total_view, cumulative_conf, max_conf and max_other_conf are required for this rule");
     EnvState st{};
     st.maps = *maps;
     st.bound = 1;
@@ -527,12 +561,37 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
     if (f->logits && c.n_classes < 1) return fail(SSMAP_ERR_INVALID_ARG, "engine was created without classes");
     if (!prob_rule) {
         if (!f->semantic) return fail(SSMAP_ERR_INVALID_ARG, "semantic is required for this rule");
-        const bool needs_unc = (r == SSMAP_RULE_PROB_HV) || ((r == SSMAP_RULE_ARGMAX || r == SSMAP_RULE_GOAL_DECAY) && v.prm.use_filter);
+        const bool needs_unc = (r == SSMAP_RULE_PROB_HV) || ((r == SSMAP_RULE_ARGMAX || r == SSMAP_RULE_STUBBORN || r == SSMAP_RULE_GOAL_DECAY) && v.prm.use_filter);
         if (needs_unc && !f->semantic_unc) return fail(SSMAP_ERR_INVALID_ARG, "semantic_unc is required for this rule");
         const bool needs_maxp = (r == SSMAP_RULE_PROB_HV) || (r == SSMAP_RULE_HV && v.prm.use_filter);
         if (needs_maxp && !f->semantic_max_prob) return fail(SSMAP_ERR_INVALID_ARG, "semantic_max_prob is required for this rule");
     }
     if (r != SSMAP_RULE_DIRECT && !f->semantic_gt) return fail(SSMAP_ERR_INVALID_ARG, "semantic_gt is required in probabilistic mode");
+    const bool goal_stats = r == SSMAP_RULE_STUBBORN || (r == SSMAP_RULE_ARGMAX && v.prm.nb_stats);
+    v.nb_probs = nullptr;
+    if (goal_stats) {
+        if (c.n_classes < 1 || !eng->have_schema)
+            return fail(SSMAP_ERR_NOT_READY, "the goal statistics need the class count and ssmap_set_schema (goal class lists)");
+        if (!f->probs && !f->logits) return fail(SSMAP_ERR_INVALID_ARG, "semantic_prob (or logits) is required for the goal statistics");
+        for (int e = 0; e < c.n_envs; ++e) {
+            const int g = f->goal_sem_id[e];
+            if (g < 3 || g > 8) return fail(SSMAP_ERR_INVALID_ARG, "goal id outside [3, 8]");
+            if (r == SSMAP_RULE_STUBBORN && !eng->nb_set[g - 3])
+                return fail(SSMAP_ERR_NOT_READY, "no naive-Bayes model for this goal (ssmap_set_nb_model)");
+            const ssmap_env_maps &mp = eng->envs[e].maps;
+            if (!mp.total_view || !mp.cumulative_conf || !mp.max_conf || !mp.max_other_conf)
+                return fail(SSMAP_ERR_INVALID_ARG, "the goal statistics maps are not bound");
+        }
+        if (f->probs) {
+            v.nb_probs = f->probs;
+        } else {
+            if (!eng->d_nb_probs) {   // first step fed with logits: room for one batch of probabilities
+                rc = dev_alloc(&eng->d_nb_probs, (size_t)v.E * v.C * v.N);
+                if (rc != SSMAP_OK) return rc;
+            }
+            v.nb_probs = eng->d_nb_probs;
+        }
+    }
 
     // ---- pose preparation on the host (a few hundred flops per env)
     const bool packed = c.n_envs <= kPosePack;
@@ -578,7 +637,7 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         MARK(3);
         launch_update_prob(v, *f, stream);
     } else {
-        if (f->logits) launch_stream(v, *f, false, nullptr, stream);
+        if (f->logits) launch_stream(v, *f, false, goal_stats ? eng->d_nb_probs : nullptr, stream);
         MARK(3);
         launch_label_rules(v, *f, stream);
     }

@@ -37,6 +37,65 @@ __device__ inline float raise_height(const View &v, const ssmap_env_maps &mp, co
     return hn;
 }
 
+// numpy's maximum / max: a NaN on either side wins
+__device__ inline float nan_max(float a, float b) {
+    return a != a ? a : (b != b ? b : fmaxf(a, b));
+}
+
+// The goal statistics of one update cell (mapper.py:449-469) and, for the stubborn rule, the
+// naive-Bayes verdict on them (mapper.py:502-515): returns false when the model says "not the goal".
+// `pr` points at the pixel's probability in class plane 0; planes are N floats apart.
+__device__ inline bool goal_statistics(const View &v, const ssmap_env_maps &mp, const float *pr, int cell, int goal) {
+    const int g = goal - 3;
+    const int n_pool = v.pool_count[g];
+    const int32_t *pool = v.pool_ids + g * SSMAP_MAX_POOL;
+    // sum of the goal classes' probabilities in list order, float32 (numpy reduces the gathered
+    // columns one after the other)
+    float pv[SSMAP_MAX_POOL];
+#pragma unroll
+    for (int k = 0; k < SSMAP_MAX_POOL; ++k) pv[k] = k < n_pool ? pr[(int64_t)pool[k] * v.N] : 0.0f;
+    float mass = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SSMAP_MAX_POOL; ++k)
+        if (k < n_pool) mass = mass + pv[k];
+    // largest probability among the other classes
+    unsigned long long in_pool[4] = {0ull, 0ull, 0ull, 0ull};
+    for (int k = 0; k < n_pool; ++k) in_pool[pool[k] >> 6] |= 1ull << (pool[k] & 63);
+    float other = 0.0f;
+    bool first = true;
+    for (int c = 0; c < v.C; ++c) {
+        if ((in_pool[c >> 6] >> (c & 63)) & 1ull) continue;
+        const float p = pr[(int64_t)c * v.N];
+        other = first ? p : nan_max(other, p);
+        first = false;
+    }
+    const uint32_t views = mp.total_view[cell] + 1u;
+    const float cum = mp.cumulative_conf[cell] + mass;
+    const float mx = nan_max(mp.max_conf[cell], mass);
+    const float mo = nan_max(mp.max_other_conf[cell], other);
+    mp.total_view[cell] = views;
+    mp.cumulative_conf[cell] = cum;
+    mp.max_conf[cell] = mx;
+    mp.max_other_conf[cell] = mo;
+    if (v.rule != SSMAP_RULE_STUBBORN) return true;
+    const NbModel &m = v.nb[g];
+    const double x[4] = {(double)views, (double)cum, (double)mx, (double)mo};
+    double best = 0.0;
+    int label = 1;
+    for (int k = 0; k < m.n_classes; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double d = x[j] - m.theta[k][j];
+            s = s + (d * d) / m.var[k][j];
+        }
+        const double jll = m.log_prior[k] + (m.konst[k] - 0.5 * s);
+        // numpy argmax: the first largest, a NaN counting as largest
+        if (k == 0 || jll > best || (jll != jll && best == best)) { best = jll; label = m.classes[k]; }
+    }
+    return label != 0;
+}
+
 // hv rules rebuild semantic_map from background_map every frame (mapper.py:662, 723); the
 // engine keeps semantic_map == background_map except on the cells listed here, and undoes
 // last frame's list instead of copying the whole map.
@@ -100,10 +159,14 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
         }
         mp.gt_map[cell] = (uint32_t)gtv;
 
-        if (v.rule == SSMAP_RULE_ARGMAX) {
+        if (v.rule == SSMAP_RULE_ARGMAX || v.rule == SSMAP_RULE_STUBBORN) {
             if (unc) mp.unc_map[cell] = unc_v;
             if (v.prm.use_filter && id == goal && (1.0f - unc_v) < v.prm.filter_goal_prob) id = 0;
             id = occupancy_override(id, h, v.use_height, v.n_schema);
+            if (v.nb_probs) {   // stubborn, or argmax collecting the statistics
+                const bool keep = goal_statistics(v, mp, v.nb_probs + (int64_t)e * v.C * v.N + pix, cell, goal);
+                if (!keep && id == goal) id = 2;
+            }
             mp.semantic_map[cell] = (uint32_t)id;
             paint(mp, v.palette, cell, id);
             continue;

@@ -73,6 +73,17 @@ struct GeomPart {
     int32_t rmin, rmax, cmin, cmax;       // box of the cells of the spilled pixels
 };
 
+// Gaussian naive Bayes over four features, as sklearn evaluates it: for class k
+//   jll_k = log(prior_k) + (konst_k - 0.5 * sum_j (x_j - theta_kj)^2 / var_kj),
+//   konst_k = -0.5 * sum_j log(2 pi var_kj); prediction = label of the first largest jll.
+struct NbModel {
+    double theta[2][4], var[2][4];
+    double log_prior[2], konst[2];
+    int32_t classes[2];
+    int32_t n_classes;       // 0 = no model set
+    int32_t pad;
+};
+
 struct EnvState {
     ssmap_env_maps maps;
     uint32_t n_overlay_prev;   // unused on host; kept for alignment
@@ -119,6 +130,8 @@ struct View {
     const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
     const int32_t *pool_count; // [6]
     int32_t pool_trivial;      // no goal id pools more than one class
+    const NbModel *nb;         // [6] by goal id - 3 (stubborn rule)
+    const float *nb_probs;     // [E][C][N] class probabilities of this step for the goal statistics
     const uint8_t *palette;    // [n][3]
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;

@@ -65,7 +65,7 @@ class RuleParams:
     """Attributes callers overwrite after construction; every write marks them dirty so the
     next step re-sends them."""
     _FIELDS = ("entropy_threshold", "filter_goal_prob", "goal_decay", "goal_mark", "hv_ratio",
-               "hv_min_views", "hv_limit_obj_view_dist", "found_dist_m")
+               "hv_min_views", "hv_limit_obj_view_dist", "found_dist_m", "collect_nb_data")
 
     def __init__(self, **kw):
         object.__setattr__(self, "dirty", True)
@@ -87,6 +87,7 @@ class RuleParams:
         p.hv_min_views = float(self.hv_min_views)
         p.hv_limit_obj_view_dist = float(self.hv_limit_obj_view_dist)
         p.found_dist_m = float(self.found_dist_m)
+        p.nb_stats = 1 if self.collect_nb_data else 0
         return p
 
 
@@ -98,7 +99,8 @@ class MapEngine:
                  probablistic_mapping: bool = False, prob_aggregate: str = "height_map_argmax",
                  seg_model_n_classes: Optional[int] = None, max_map_hw=(480, 480),
                  entropy_threshold: float = 0.5, success_dist_m: float = 1.0,
-                 filter_goal_prob: Optional[float] = None, device="cuda:0"):
+                 filter_goal_prob: Optional[float] = None, collect_nb_data: bool = False,
+                 device="cuda:0"):
         self.lib = _capi.load()
         if not torch.cuda.is_available():
             raise RuntimeError("MapEngine needs a GPU: the fusion path has no CPU fallback")
@@ -116,7 +118,9 @@ class MapEngine:
         self.max_map_hw = (int(max_map_hw[0]), int(max_map_hw[1]))
         self.params = RuleParams(entropy_threshold=entropy_threshold, filter_goal_prob=filter_goal_prob,
                                  goal_decay=0.9, goal_mark=2.0, hv_ratio=0.5, hv_min_views=10,
-                                 hv_limit_obj_view_dist=0.0, found_dist_m=success_dist_m)
+                                 hv_limit_obj_view_dist=0.0, found_dist_m=success_dist_m,
+                                 collect_nb_data=bool(collect_nb_data))
+        self.collect_nb_data = bool(collect_nb_data)
         fx, fy = focal_lengths(self.img_h, self.img_w, depth_hfov)
         cfg = _capi.Config(
             n_envs=self.n_envs, img_h=self.img_h, img_w=self.img_w, n_classes=self.n_classes,
@@ -224,6 +228,28 @@ class MapEngine:
                                                   ids.ctypes.data, cnt.ctypes.data))
         self.schema_lut = lut
 
+    # ---- naive-Bayes models of the stubborn rule (mapper.py:184-191, 502-515)
+    def set_nb_model(self, goal_sem_id: int, model):
+        """`model`: a fitted sklearn GaussianNB, or any object / dict with its `classes_`,
+        `class_prior_`, `theta_` and `var_` (four features: total_view, cumulative_conf, max_conf,
+        max_other_conf).  The constants are derived here exactly as sklearn's
+        _joint_log_likelihood derives them."""
+        get = (lambda k: model[k]) if isinstance(model, dict) else (lambda k: getattr(model, k))
+        classes = np.ascontiguousarray(np.asarray(get("classes_")), dtype=np.int32)
+        prior = np.asarray(get("class_prior_"), dtype=np.float64)
+        theta = np.ascontiguousarray(np.asarray(get("theta_"), dtype=np.float64))
+        var = np.ascontiguousarray(np.asarray(get("var_"), dtype=np.float64))
+        n = classes.shape[0]
+        if theta.shape != (n, 4) or var.shape != (n, 4) or prior.shape != (n,):
+            raise ValueError("naive-Bayes model: theta_, var_ must be [n_classes, 4]")
+        log_prior = np.ascontiguousarray([np.log(prior[i]) for i in range(n)], dtype=np.float64)
+        konst = np.ascontiguousarray([-0.5 * np.sum(np.log(2.0 * np.pi * var[i, :])) for i in range(n)],
+                                     dtype=np.float64)
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.ssmap_set_nb_model(self._h, int(goal_sem_id), int(n), classes.ctypes.data,
+                                                    log_prior.ctypes.data, konst.ctypes.data,
+                                                    theta.ctypes.data, var.ctypes.data))
+
     # ---- reset (mapper.py:193-269)
     def reset_env(self, e: int, map_bounds):
         b = np.asarray(map_bounds, dtype=np.float64)
@@ -250,6 +276,12 @@ class MapEngine:
                 m["views"] = torch.zeros((rows, cols), dtype=f32, device=dev)
         else:
             m["gt_map"] = m["semantic_map"]
+        if (self.probablistic_mapping and self.rule == "stubborn") or self.collect_nb_data:
+            # mapper.py:244-250, 260-264
+            m["total_view"] = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
+            m["cumulative_conf"] = torch.zeros((rows, cols), dtype=f32, device=dev)
+            m["max_conf"] = torch.zeros((rows, cols), dtype=f32, device=dev)
+            m["max_other_conf"] = torch.zeros((rows, cols), dtype=f32, device=dev)
 
         def ptr(name):
             t = m.get(name)
@@ -268,6 +300,10 @@ class MapEngine:
         em.background_map = ptr("background_map")
         em.hits = ptr("hits")
         em.views = ptr("views")
+        em.total_view = ptr("total_view")
+        em.cumulative_conf = ptr("cumulative_conf")
+        em.max_conf = ptr("max_conf")
+        em.max_other_conf = ptr("max_other_conf")
         with torch.cuda.device(self.device):
             torch.cuda.current_stream().synchronize()   # fills above are stream ordered
             _capi.check(self.lib.ssmap_bind_env(self._h, int(e), C.byref(em)))

@@ -6,7 +6,9 @@ sem_objnav/obj_nav/mapper.py:48-269, so the callers (`MappingObjNavEnv`, env.py:
 reference class.  Observations arrive as numpy arrays (one frame), are copied to the GPU,
 fused there, and the map arrays are copied back only when a caller reads them.
 
-Not built yet: the path overlay (mapper.py:822-833) and the "stubborn" rule.
+The "stubborn" rule takes its naive-Bayes models as fitted arrays (`nb_models`, or a JSON file
+written by tools/export_nb_models.py) instead of the reference's pickle (mapper.py:184-191).
+Not built yet: the path overlay (mapper.py:822-833).
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ from . import engine as _engine
 
 _MAP_NAMES = ("semantic_map", "semantic_map_color", "height_map", "gt_map", "unc_map", "goal_map",
               "log_odds_seg_map", "avg_prob_seg_map", "avg_prob_weight_map", "background_map",
-              "hits", "views")
+              "hits", "views", "total_view", "cumulative_conf", "max_conf", "max_other_conf")
 _RULE_ATTRS = ("entropy_threshold", "goal_decay", "goal_mark", "hv_ratio", "hv_min_views",
                "hv_limit_obj_view_dist")
 
@@ -79,6 +81,25 @@ def fp_fn_detections(semantic_map, gt_map, goal_sem_id, centers, sizes, lower, p
     return int(fp), fn, is_fn
 
 
+def _load_nb_models(nb_models, model_name):
+    """{goal id: model} from a dict of fitted models or from a JSON file
+    {"<goal id>": {"classes_": [...], "class_prior_": [...], "theta_": [[...]], "var_": [[...]]}}."""
+    import json
+    import os
+    if nb_models is None and model_name is not None:
+        nb_models = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nb_models", f"{model_name}.json")
+    if nb_models is None:
+        raise ValueError("the stubborn rule needs nb_models (fitted GaussianNB per goal id) or model_name")
+    if isinstance(nb_models, (str, os.PathLike)):
+        if not os.path.exists(nb_models):
+            raise FileNotFoundError(
+                f"{nb_models}: export the reference's naive-Bayes models to JSON first "
+                "(tools/export_nb_models.py, run where the pickle can be trusted)")
+        with open(nb_models) as fh:
+            nb_models = {int(k): v for k, v in json.load(fh).items()}
+    return dict(nb_models)
+
+
 class SemanticMapper:
     def __init__(
         self,
@@ -104,6 +125,7 @@ class SemanticMapper:
         collect_nb_data: bool = False,
         model_name: Optional[str] = None,
         device: str = "cuda:0",
+        nb_models=None,
     ):
         self.pixel2meter = pixel2meter
         self.depth_range = depth_range
@@ -129,8 +151,12 @@ class SemanticMapper:
         self.num_semantic_classes = num_semantic_classes
         self.prob_aggregate = prob_aggregate
         self.found_dist_m = success_dist_m
-        if prob_aggregate in ("height_map_stubborn", "stubborn") or collect_nb_data:
-            raise NotImplementedError("the stubborn rule and NB-data collection are not built")
+        self.nb_models = None
+        if prob_aggregate in ("height_map_stubborn", "stubborn"):
+            # the reference unpickles nb_models/<model_name>.pkl here (mapper.py:184-191); this class
+            # takes the fitted models themselves: {goal id: GaussianNB-like}, or the path of a JSON
+            # file holding classes_, class_prior_, theta_, var_ per goal id
+            self.nb_models = _load_nb_models(nb_models, model_name)
         self._rule, self._use_height = _engine.split_rule(prob_aggregate, probablistic_mapping)
         # rule constants exist only for the rule that uses them, as in the reference
         # (mapper.py:145-169); callers test them with hasattr (eval_objnav.py:118-129)
@@ -177,7 +203,10 @@ class SemanticMapper:
                 depth_range=self.depth_range, pixel2meter=self.pixel2meter,
                 height_cutoff_m=self.height_cutoff_m, probablistic_mapping=self.probablistic_mapping,
                 prob_aggregate=self.prob_aggregate, seg_model_n_classes=self.sem_model_n_classes,
-                max_map_hw=(rows, cols), success_dist_m=self.found_dist_m, device=self._device)
+                max_map_hw=(rows, cols), success_dist_m=self.found_dist_m,
+                collect_nb_data=self.collect_nb_data, device=self._device)
+            for goal, model in (self.nb_models or {}).items():
+                eng.set_nb_model(int(goal), model)
             eng.set_egomap(self._ego_cfg["egomap_small_side_m"], self._ego_cfg["egomap_large_side_m"],
                            self.egomap_size, self._ego_cfg["agent_draw_radius_m"], self.aux_bin_number,
                            self._ego_cfg["aux_radius_m"], self._ego_cfg["aux_bin_m"], self.offset_for_cut)
@@ -206,6 +235,8 @@ class SemanticMapper:
 
     # ------------------------------------------------------------------ reference interface
     def reset(self, map_bounds: np.ndarray):
+        if self.collect_nb_data:
+            self.eps_nb_data = {"goal": [], "non_goal": [], "goal_id": None}   # mapper.py:265
         self.map_bounds = np.asarray(map_bounds)
         self._bound = False
         self._host_cache = {}
@@ -240,6 +271,8 @@ class SemanticMapper:
                 kwargs["semantic"] = up("semantic", np.int32)
                 kwargs["semantic_unc"] = up("semantic_unc", np.float32)
                 kwargs["semantic_max_prob"] = up("semantic_max_prob", np.float32)
+                if self._rule == "stubborn" or self.collect_nb_data:
+                    kwargs["probs"] = up("semantic_prob", np.float32)
         else:
             kwargs["semantic"] = up("semantic", np.int32)
         eng.step(d_depth, obs["agent_position_and_rotation"], obs["camera_position_and_rotation"],
@@ -251,6 +284,8 @@ class SemanticMapper:
         self.last_status, self.last_n_updates = int(status[0]), int(n_upd[0])
         if status[0] & 1:
             raise IndexError("index out of bounds for the semantic map (cell index below -dim)")
+        if self.collect_nb_data and self.probablistic_mapping and self._rule in ("argmax", "stubborn"):
+            self._collect_nb_rows(eng, goal_id)
         lower = self.map_bounds[:3]
         self.prev_pos_px = self.world2map(np.asarray(obs["agent_position_and_rotation"])[:3], lower)
         is_found = True if found[0] else None
@@ -261,6 +296,23 @@ class SemanticMapper:
         ego = (small[0].cpu().numpy(), large[0].cpu().numpy(),
                None if unc_s is None else unc_s[0].cpu().numpy(), None if unc_l is None else unc_l[0].cpu().numpy())
         return ego, is_found
+
+    def _collect_nb_rows(self, eng, goal_id):
+        """Feature rows of this frame's update cells for fitting the naive-Bayes models
+        (mapper.py:470-500): one [k, 4] float64 array of the cells whose ground truth is the goal;
+        the other cells' rows only when no update cell is a goal cell."""
+        pix, cells = eng.update_list(0, self.last_n_updates)     # ascending pixel order, like valid_flat_idx
+        maps = eng.maps[0]
+        idx = torch.from_numpy(cells).to(eng.device)
+        cols = [maps[name].reshape(-1)[idx].cpu().numpy() for name in
+                ("total_view", "cumulative_conf", "max_conf", "max_other_conf")]
+        cols[0] = cols[0].view(np.uint32)
+        is_goal = maps["gt_map"].reshape(-1)[idx].cpu().numpy().view(np.uint32) == goal_id
+        if is_goal.any():
+            self.eps_nb_data["goal"].append(np.stack([c[is_goal] for c in cols], axis=-1))
+        if not is_goal.any():
+            self.eps_nb_data["non_goal"].append(np.stack([c[~is_goal] for c in cols], axis=-1))
+        self.eps_nb_data["goal_id"] = goal_id
 
     def _disk_indices(self, center):
         """Row/column index arrays of the found disk (mapper.py:737-743, 785)."""

@@ -100,6 +100,17 @@ CASES = [
     # give exact height ties inside a cell (tie -> lowest pixel index)
     dict(name="height_ties", rule="height_map_argmax", prob=False, C=0, hw=(48, 64),
          frames=2, scene="room", start=(2.2, 3.6), step=0.3, yaw=0.0, quantum=0.25),
+    # stubborn: argmax + goal statistics + the naive-Bayes veto; goal classes 3 and 9 pooled
+    dict(name="stubborn_nb", rule="height_map_stubborn", prob=True, C=12, hw=(60, 80),
+         frames=5, scene="room", start=(1.0, 1.0), step=0.45, yaw=YAW_IN, sharp=3.0,
+         nb=True, goal_classes={3: [3, 9]}),
+    dict(name="stubborn_nb_filter", rule="stubborn", prob=True, C=8, hw=(48, 64),
+         frames=4, scene="room", start=(1.0, 1.0), step=0.5, yaw=YAW_IN, sharp=2.0,
+         filter_goal_prob=0.3, nb=True, goal_classes={3: [3]}),
+    # argmax collecting the training rows of those models
+    dict(name="argmax_collect_nb", rule="height_map_argmax", prob=True, C=8, hw=(60, 80),
+         frames=4, scene="room", start=(1.0, 1.0), step=0.5, yaw=YAW_IN,
+         collect=True, goal_classes={3: [3]}),
     dict(name="uniform_goal_decay", rule="height_map_goal_decay", prob=True, C=6, hw=(48, 64),
          frames=3, scene="uniform", start=(2.2, 2.2), step=0.0, yaw=2.0, turn=0.5,
          filter_goal_prob=0.3),
@@ -136,13 +147,49 @@ def build_frames(case):
     return frames, lut
 
 
+def fit_nb_models(seed):
+    """Fitted sklearn GaussianNB per goal id on synthetic feature rows {views, cumulative,
+    max goal confidence, max other confidence}; label 1 = really the goal."""
+    from sklearn.naive_bayes import GaussianNB
+    rng = np.random.default_rng(seed)
+    models = {}
+    for goal in range(3, 9):
+        n = 400
+        views1 = rng.integers(1, 6, n)
+        conf1 = np.clip(rng.normal(0.62, 0.12, n), 0.05, 1.0)
+        views0 = rng.integers(1, 6, n)
+        conf0 = np.clip(rng.normal(0.40, 0.10, n), 0.02, 1.0)
+        x1 = np.stack([views1, views1 * conf1 * 0.9, conf1, np.clip(1 - conf1 - 0.1, 0.01, 1)], -1)
+        x0 = np.stack([views0, views0 * conf0 * 0.8, conf0, np.clip(1 - conf0 - 0.2, 0.01, 1)], -1)
+        models[goal] = GaussianNB().fit(np.concatenate([x0, x1]), np.concatenate([np.zeros(n), np.ones(n)]).astype(int))
+    return models
+
+
 def run_case(ref, case):
     frames, lut = build_frames(case)
     c = case["C"]
-    mapper = ref.SemanticMapper(
-        num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
-        probablistic_mapping=case["prob"], prob_aggregate=case["rule"],
-        seg_model_n_classes=c or None, filter_goal_prob=case.get("filter_goal_prob"))
+    nb_models = None
+    kw = {}
+    if case.get("nb"):
+        # the reference unpickles nb_models/<model_name>.pkl in its constructor (mapper.py:184-191);
+        # that file is opened but never read here: pickle.load is replaced for the call and hands
+        # over models fitted by this script
+        nb_models = fit_nb_models(len(case["name"]))
+        kw["model_name"] = "emsanet"
+        real_load = ref.pickle.load
+        ref.pickle.load = lambda fh: nb_models
+    if case.get("collect"):
+        kw["collect_nb_data"] = True
+    try:
+        mapper = ref.SemanticMapper(
+            num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+            probablistic_mapping=case["prob"], prob_aggregate=case["rule"],
+            seg_model_n_classes=c or None, filter_goal_prob=case.get("filter_goal_prob"), **kw)
+    finally:
+        if case.get("nb"):
+            ref.pickle.load = real_load
+    if "goal_classes" in case:
+        mapper.objnav_to_sem_pred = {int(k): list(v) for k, v in case["goal_classes"].items()}
     for k, v in case.get("attrs", {}).items():
         setattr(mapper, k, v)
     if lut is not None:
@@ -153,13 +200,22 @@ def run_case(ref, case):
     meta = dict(name=case["name"], rule=case["rule"], prob=case["prob"], C=c,
                 hw=list(case["hw"]), n_frames=len(frames), bounds=BOUNDS,
                 filter_goal_prob=case.get("filter_goal_prob"), attrs=case.get("attrs", {}),
+                collect_nb_data=bool(case.get("collect")),
+                goal_classes={str(k): list(v) for k, v in case.get("goal_classes", {}).items()},
+                nb_models=None if nb_models is None else {
+                    str(g): dict(classes_=[int(v) for v in m.classes_],
+                                 class_prior_=[float(v) for v in m.class_prior_],
+                                 theta_=[[float(v) for v in r] for r in m.theta_],
+                                 var_=[[float(v) for v in r] for r in m.var_])
+                    for g, m in nb_models.items()},
                 lut=None if lut is None else [int(v) for v in lut],
                 numpy=np.__version__)
     for i, (fr, agent, cam) in enumerate(frames):
         obs = scenes.make_obs(fr, agent, cam, goal_index=0)
         # keep only the observation keys this rule reads (mapper.py:361-727)
         uses_probs = any(t in case["rule"] for t in ("avg_prob", "log_odds"))
-        if case["prob"] and not uses_probs:
+        keeps_probs = bool(case.get("nb") or case.get("collect"))   # goal statistics read semantic_prob
+        if case["prob"] and not uses_probs and not keeps_probs:
             obs.pop("semantic_prob", None)
             if "prob_hv" in case["rule"]:   # mapper.py:668 only transposes it
                 obs["semantic_prob"] = np.zeros((1,) + obs["depth"].shape, dtype=np.float32)
@@ -168,7 +224,7 @@ def run_case(ref, case):
                 obs.pop(key, None)
         for key in ("depth", "semantic", "semantic_gt", "semantic_prob", "semantic_unc",
                     "semantic_max_prob"):
-            if key in obs and not (key == "semantic_prob" and not uses_probs):
+            if key in obs and not (key == "semantic_prob" and not (uses_probs or keeps_probs)):
                 out[f"f{i}_in_{key}"] = obs[key].copy()
         out[f"f{i}_in_agent"] = agent
         out[f"f{i}_in_camera"] = cam
@@ -200,10 +256,16 @@ def run_case(ref, case):
                     [val[finite].astype(np.float64).sum(), float(finite.sum())])
     for name in ("semantic_map", "semantic_map_color", "height_map", "gt_map", "unc_map",
                  "goal_map", "log_odds_seg_map", "avg_prob_seg_map", "avg_prob_weight_map",
-                 "background_map", "hits", "views"):
+                 "background_map", "hits", "views", "total_view", "cumulative_conf", "max_conf",
+                 "max_other_conf"):
         val = getattr(mapper, name, None)
         if val is not None:
             out[f"final_{name}"] = val.copy()
+    if case.get("collect"):
+        for key in ("goal", "non_goal"):
+            rows = mapper.eps_nb_data[key]
+            out[f"final_nb_{key}"] = np.concatenate(rows) if rows else np.zeros((0, 4))
+            out[f"final_nb_{key}_chunks"] = np.array([len(r) for r in rows], dtype=np.int64)
     out["meta"] = np.array(json.dumps(meta))
     return out
 

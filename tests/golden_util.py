@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FLOAT_STATE = ("height_map", "unc_map", "goal_map", "hits", "views")
 FINAL_NAMES = ("semantic_map", "semantic_map_color", "height_map", "gt_map", "unc_map", "goal_map",
                "log_odds_seg_map", "avg_prob_seg_map", "avg_prob_weight_map", "background_map",
-               "hits", "views")
+               "hits", "views", "total_view", "cumulative_conf", "max_conf", "max_other_conf")
 
 
 def case_names():
@@ -31,9 +31,23 @@ class GoldenCase:
 
     def mapper_kwargs(self):
         m = self.meta
-        return dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
-                    probablistic_mapping=m["prob"], prob_aggregate=m["rule"],
-                    seg_model_n_classes=m["C"] or None, filter_goal_prob=m["filter_goal_prob"])
+        kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                  probablistic_mapping=m["prob"], prob_aggregate=m["rule"],
+                  seg_model_n_classes=m["C"] or None, filter_goal_prob=m["filter_goal_prob"])
+        if m.get("collect_nb_data"):
+            kw["collect_nb_data"] = True
+        if m.get("nb_models"):
+            kw["nb_models"] = {int(g): v for g, v in m["nb_models"].items()}
+        return kw
+
+    def goal_classes(self):
+        """objnav_to_sem_pred of the case ({goal id: model classes}), or None."""
+        gc = self.meta.get("goal_classes")
+        return {int(g): list(v) for g, v in gc.items()} if gc else None
+
+    def nb_rows(self, key):
+        k = f"final_nb_{key}"
+        return (self.data[k], self.data[k + "_chunks"]) if k in self.data.files else None
 
     def obs(self, i):
         pre = f"f{i}_in_"

@@ -27,8 +27,8 @@ def test_struct_sizes_match_the_header_layout():
     import semantic_search_amd as ssa
     c = ssa._capi
     assert ctypes.sizeof(c.Config) == 9 * 4 + 2 * 4 + 4 + 4 * 8      # 9 ints, 2 floats, pad, 4 doubles
-    assert ctypes.sizeof(c.EnvMaps) == 8 + 3 * 8 + 11 * 8
-    assert ctypes.sizeof(c.Params) == 7 * 4 + 4 + 2 * 8
+    assert ctypes.sizeof(c.EnvMaps) == 8 + 3 * 8 + 15 * 8
+    assert ctypes.sizeof(c.Params) == 7 * 4 + 4 + 2 * 8 + 2 * 4
     assert ctypes.sizeof(c.Frames) == 11 * 8
 
 

@@ -261,6 +261,49 @@ def test_frame_of_more_than_a_million_pixels():
     eng.close()
 
 
+def test_stubborn_rule_from_logits_equals_stubborn_from_stage1_outputs():
+    """height_map_stubborn, C = 40, two engines over the same frames: one is fed logits (stage 1
+    runs inside the step and leaves the probabilities for the goal statistics), the other the
+    stage-1 outputs as tensors.  Same maps, same statistics, and the model vetoes some goal cells."""
+    import semantic_search_amd as ssa
+    from tests import golden_util as gu
+    h, w, c, temp = 120, 160, 40, 3.2
+    lut = scenes.schema_lut(c)
+    model = gu.GoldenCase("stubborn_nb").mapper_kwargs()["nb_models"][3]
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_stubborn", seg_model_n_classes=c)
+    engines = []
+    for _ in range(2):
+        eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
+        eng.set_schema(lut)
+        eng.set_nb_model(3, model)
+        engines.append((eng, eng.reset_env(0, BOUNDS_480)))
+    rng, prng = np.random.default_rng(51), np.random.default_rng(52)
+    for i in range(3):
+        frame = scenes.uniform_frame(rng, h, w, c, temp, lut=lut, with_probs=False)
+        agent, cam = scenes.make_pose(7.2, 0.0, 7.2, prng.uniform(0, 2 * np.pi))
+        logits = _to_dev(frame["logits"][None], np.float32)
+        gt = _to_dev(frame["semantic_gt"][None], np.int32)
+        (ea, _), (eb, _) = engines
+        sem = torch.empty((1, h, w), dtype=torch.int32, device="cuda")
+        unc = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        maxp = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+        ea.step(_to_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3], logits=logits,
+                temperature=temp, semantic=sem, semantic_unc=unc, semantic_max_prob=maxp, semantic_gt=gt)
+        st = eb.stage1(logits, temp, want_probs=True)
+        eb.step(_to_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                probs=st["semantic_prob"], semantic=st["semantic"], semantic_unc=st["semantic_unc"],
+                semantic_max_prob=st["semantic_max_prob"], semantic_gt=gt)
+        assert not ea.results()[1].any() and not eb.results()[1].any()
+    ma, mb = engines[0][1], engines[1][1]
+    for name in ("semantic_map", "height_map", "gt_map", "unc_map", "total_view", "cumulative_conf",
+                 "max_conf", "max_other_conf"):
+        assert torch.equal(ma[name], mb[name]), name
+    assert int(ma["total_view"].max()) >= 2
+    for eng, _ in engines:
+        eng.close()
+
+
 def test_segformer_style_150_classes_w2():
     eng, maps, ref, log = _run_pair("height_map_w2_avg_prob", 150, 2.5, 2, (120, 160), True,
                                     attrs=dict(entropy_threshold=0.482), bounds=BOUNDS_480)

@@ -12,7 +12,7 @@ from tests import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-5, 1e-6
-EXACT = ("semantic_map", "semantic_map_color", "gt_map", "background_map", "height_map")
+EXACT = ("semantic_map", "semantic_map_color", "gt_map", "background_map", "height_map", "total_view")
 
 
 def _close(got, want, name):
@@ -38,6 +38,8 @@ def test_engine_matches_reference_golden(name):
     if case.meta["lut"] is not None:
         lut = np.asarray(case.meta["lut"])
         mapper.map_seg_to_schema = lambda ids: lut[ids]
+    if case.goal_classes() is not None:
+        mapper.objnav_to_sem_pred = case.goal_classes()
     mapper.reset(np.array(case.meta["bounds"], dtype=np.float64))
     for i in range(case.n_frames):
         obs = case.obs(i)
@@ -57,3 +59,11 @@ def test_engine_matches_reference_golden(name):
             assert np.array_equal(got, want), nm
         else:
             _close(got, want, nm)
+    for key in ("goal", "non_goal"):
+        want = case.nb_rows(key)
+        if want is not None:
+            rows = mapper.eps_nb_data[key]
+            assert [len(r) for r in rows] == list(want[1]), key
+            got = np.concatenate(rows) if rows else np.zeros((0, 4))
+            assert got.dtype == np.float64
+            _close(got, want[0], "eps_nb_data " + key)

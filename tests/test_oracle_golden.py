@@ -13,7 +13,8 @@ from tests import golden_util as gu
 @pytest.mark.parametrize("name", gu.case_names())
 def test_oracle_matches_reference_golden(name):
     case = gu.GoldenCase(name)
-    mapper = mo.OracleMapper(schema_lut=case.meta["lut"], **case.mapper_kwargs())
+    mapper = mo.OracleMapper(schema_lut=case.meta["lut"], objnav_to_sem_pred=case.goal_classes(),
+                             **case.mapper_kwargs())
     for k, v in case.meta["attrs"].items():
         setattr(mapper, k, v)
     mapper.reset(np.array(case.meta["bounds"], dtype=np.float64))
@@ -33,6 +34,25 @@ def test_oracle_matches_reference_golden(name):
         want = case.final(nm)
         if want is not None:
             assert np.array_equal(getattr(mapper, nm), want, equal_nan=True), nm
+    for key in ("goal", "non_goal"):
+        want = case.nb_rows(key)
+        if want is not None:
+            rows = mapper.eps_nb_data[key]
+            assert [len(r) for r in rows] == list(want[1]), key
+            got = np.concatenate(rows) if rows else np.zeros((0, 4))
+            assert got.dtype == np.float64 and np.array_equal(got, want[0]), key
+
+
+def test_naive_bayes_restatement_vetoes_some_goal_cells():
+    """The stubborn fixtures really exercise both verdicts of the model."""
+    case = gu.GoldenCase("stubborn_nb")
+    model = case.mapper_kwargs()["nb_models"][3]
+    tv, cc = case.final("total_view").reshape(-1), case.final("cumulative_conf").reshape(-1)
+    seen = tv > 0
+    feats = np.stack([tv[seen], cc[seen], case.final("max_conf").reshape(-1)[seen],
+                      case.final("max_other_conf").reshape(-1)[seen]], axis=-1)
+    pred = mo.gaussian_nb_predict(model, feats)
+    assert (pred == 0).any() and (pred == 1).any()
 
 
 def test_golden_cases_cover_edge_cases():

@@ -222,6 +222,15 @@ int ssmap_ego_maps(ssmap_engine *eng, const double *agent_pose, const int32_t *g
                    const uint8_t *aux_color, uint8_t *ego_small, uint8_t *ego_large,
                    float *unc_small, float *unc_large, void *stream);
 
+/* Path overlay (mapper.py:822-833): the cells of the agent's trail are shown as id n_schema + 1
+ * in semantic_map / semantic_map_color at the end of every update_map from the second frame on.
+ * The line raster itself (cv2.line, mapper.py:823-830) stays with the caller, who appends the
+ * cells it newly covers: cells is HOST [n], flat indices into env e's map.  ssmap_bind_env
+ * empties the list.  ssmap_path_paint stamps every listed cell of every env; call it after
+ * ssmap_step (the found decision reads the map before the trail is drawn, mapper.py:735-833). */
+int ssmap_path_append(ssmap_engine *eng, int32_t e, const int32_t *cells, int32_t n, void *stream);
+int ssmap_path_paint(ssmap_engine *eng, void *stream);
+
 const char *ssmap_last_error(void);
 const char *ssmap_version(void);
 

@@ -10,8 +10,9 @@ float64 per-pixel geometry.  Pinning: tests/test_oracle_golden.py checks this mo
 against tests/golden/*.npz, which were recorded from the reference's own mapper.py (see
 tests/golden/make_golden.py for how, and for which third-party seams are unpinned).
 
-Not restated here: ego-map rendering (mapper.py:876-998; see egomap_oracle.py) and the path
-overlay (mapper.py:822-833).
+Not restated here: ego-map rendering (mapper.py:876-998; see egomap_oracle.py).  The path
+overlay (mapper.py:822-833) is restated with a pluggable line raster (`line_fn`, default
+oracle/raster.py line: an approximation of cv2.line, like the one the fixtures were recorded with).
 """
 from __future__ import annotations
 
@@ -174,7 +175,8 @@ class OracleMapper:
                  pixel2meter=0.03, height_cutoff_m=0.1, entropy_threshold=0.5,
                  probablistic_mapping=False, prob_aggregate="height_map_argmax",
                  success_dist_m=1.0, seg_model_n_classes=None, filter_goal_prob=None,
-                 schema_lut=None, collect_nb_data=False, nb_models=None, objnav_to_sem_pred=None):
+                 schema_lut=None, collect_nb_data=False, nb_models=None, objnav_to_sem_pred=None,
+                 path_width_m=0.1, line_fn=None, path_overlay=True):
         self.num_semantic_classes = num_semantic_classes
         self.depth_hfov = depth_hfov
         self.depth_range = depth_range
@@ -187,6 +189,10 @@ class OracleMapper:
         self.filter_goal_prob = filter_goal_prob
         self.schema_lut = None if schema_lut is None else np.asarray(schema_lut)
         self.collect_nb_data = collect_nb_data
+        self.path_width_px = int(path_width_m / pixel2meter)
+        self.path_id = num_semantic_classes + 1
+        self.line_fn = line_fn or raster.line
+        self.path_overlay = path_overlay   # False: the state after the found decision, as ssmap_step leaves it
         self.nb_models = nb_models                    # {goal id: dict(classes_, class_prior_, theta_, var_)}
         self.objnav_to_sem_pred = objnav_to_sem_pred  # {goal id: model classes of that goal}
         self.use_height = prob_aggregate.startswith("height_map_")
@@ -216,6 +222,8 @@ class OracleMapper:
         self.semantic_map = np.zeros((nr, nc), u32)
         self.semantic_map_color = np.zeros((nr, nc, 3), np.uint8)
         self.height_map = np.full((nr, nc), -np.inf, f32)
+        self.path_mask = np.zeros((nr, nc), np.uint8)
+        self.prev_pos_px = None
         self.unc_map = None
         if self.collect_nb_data or (self.probablistic_mapping and self.rule == "stubborn"):
             # mapper.py:244-250, 260-265
@@ -296,7 +304,17 @@ class OracleMapper:
         if not hv_rule:
             self.semantic_map[cells] = ids
         self.semantic_map_color[cells] = self.color_pallete[self.semantic_map[cells]]
-        return self._found(agent, lower, goal_id, hv_rule)
+        found = self._found(agent, lower, goal_id, hv_rule)
+        # path overlay (mapper.py:822-839): drawn after the found decision, from the second frame on
+        robot = cell_of(agent[:3], lower, self.pixel2meter)
+        if self.prev_pos_px is not None and self.path_overlay:
+            self.path_mask = self.line_fn(self.path_mask, (self.prev_pos_px[1], self.prev_pos_px[0]),
+                                          (robot[1], robot[0]), 1, self.path_width_px)
+            on = self.path_mask.astype(bool)
+            self.semantic_map[on] = self.path_id
+            self.semantic_map_color[on] = self.color_pallete[self.path_id]
+        self.prev_pos_px = robot
+        return found
 
     # ---- rules (stage 4)
     def _fuse_argmax(self, obs, pix, cells, goal_id, agent, lower):

@@ -91,3 +91,53 @@ def dilate_max(img: np.ndarray, kh: int, kw: int) -> np.ndarray:
         for j in range(kw):
             out = np.maximum(out, pad[i : i + h, j : j + w])
     return out
+
+
+def line_cells(p0, p1, thickness: int):
+    """Cells (x, y) of a thick line from p0 to p1 (both (x, y) ints): the 8-connected centre line
+    of OpenCV's LineIterator (drawing.cpp: left to right, the error term starting at dx - 2 dy),
+    drawn with a square brush of `thickness` cells.  An APPROXIMATION of cv2.line for
+    thickness > 1 (OpenCV fills a rotated rectangle and round caps in 16.16 fixed point, which
+    is not restated here): the callers of the reference class use the real cv2.line when OpenCV
+    is importable, this function otherwise and in the fixtures."""
+    x0, y0, x1, y1 = int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1])
+    if x1 < x0:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, y1 - y0
+    ystep = -1 if dy < 0 else 1
+    dy = abs(dy)
+    pts = []
+    if dy > dx:       # y is the major axis
+        err, plus, minus = dy - 2 * dx, 2 * dy, -2 * dx
+        x, y = x0, y0
+        for _ in range(dy + 1):
+            pts.append((x, y))
+            m = err < 0
+            err += minus + (plus if m else 0)
+            y += ystep
+            x += 1 if m else 0
+    else:
+        err, plus, minus = dx - 2 * dy, 2 * dx, -2 * dy
+        x, y = x0, y0
+        for _ in range(dx + 1):
+            pts.append((x, y))
+            m = err < 0
+            err += minus + (plus if m else 0)
+            x += 1
+            y += ystep if m else 0
+    lo, hi = -((thickness - 1) // 2), thickness // 2
+    out = set()
+    for x, y in pts:
+        for oy in range(lo, hi + 1):
+            for ox in range(lo, hi + 1):
+                out.add((x + ox, y + oy))
+    return sorted(out, key=lambda c: (c[1], c[0]))
+
+
+def line(img: np.ndarray, p0, p1, color, thickness: int = 1):
+    """cv2.line stand-in on a 2-D array (see line_cells); clipped to the image, returns img."""
+    h, w = img.shape[:2]
+    for x, y in line_cells(p0, p1, max(int(thickness), 1)):
+        if 0 <= x < w and 0 <= y < h:
+            img[y, x] = color
+    return img

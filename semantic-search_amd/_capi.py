@@ -18,7 +18,7 @@ ENV_INDEX_ERROR = 1
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
            "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_stage1",
            "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
-           "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_set_nb_model", "ssmap_last_error", "ssmap_version")
+           "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_set_nb_model", "ssmap_path_append", "ssmap_path_paint", "ssmap_last_error", "ssmap_version")
 
 
 class Config(C.Structure):
@@ -96,6 +96,8 @@ def load():
     lib.ssmap_set_egomap.argtypes = [vp, C.POINTER(EgomapConfig)]
     lib.ssmap_ego_maps.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ssmap_set_nb_model.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.ssmap_path_append.argtypes = [vp, i32, vp, i32, vp]
+    lib.ssmap_path_paint.argtypes = [vp, vp]
     lib.ssmap_last_error.restype = C.c_char_p
     lib.ssmap_version.restype = C.c_char_p
     for name in EXPORTS:

@@ -113,6 +113,7 @@ struct ssmap_engine {
     uint8_t *d_palette = nullptr;
     NbModel *d_nb = nullptr;               // [6] naive-Bayes models of the stubborn rule, by goal id - 3
     bool nb_set[6] = {};
+    std::vector<uint32_t> path_n;          // host mirror of view.path_count
     float *d_nb_probs = nullptr;           // [E][C][N] stage-1 probabilities when that rule is fed logits
     int palette_rows = 0;
     bool have_params = false, have_schema = false, have_palette = false;
@@ -168,6 +169,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
     hipFree(eng->d_disk); hipFree(eng->d_palette); hipFree(eng->d_ego);
     hipFree(eng->d_nb); hipFree(eng->d_nb_probs);
+    hipFree(v.path_cells); hipFree(v.path_count);
     for (hipEvent_t ev : eng->prof_events) hipEventDestroy(ev);
     for (int i = 0; i < kPoseRing; ++i) {
         if (eng->h_ring[i]) hipHostFree(eng->h_ring[i]);
@@ -254,6 +256,11 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
     TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
     TRY_ALLOC(dev_alloc(&eng->d_pool_count, (size_t)6));
+    v.path_cap = (int64_t)c.max_map_h * c.max_map_w;
+    TRY_ALLOC(dev_alloc(&v.path_cells, (size_t)v.E * v.path_cap));
+    TRY_ALLOC(dev_alloc(&v.path_count, (size_t)v.E));
+    hipMemset(v.path_count, 0, sizeof(uint32_t) * v.E);
+    eng->path_n.assign(c.n_envs, 0u);
     TRY_ALLOC(dev_alloc(&eng->d_nb, (size_t)6));
     hipMemset(eng->d_nb, 0, 6 * sizeof(NbModel));
     v.nb = eng->d_nb;
@@ -385,6 +392,39 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
     const uint32_t zero = 0;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(hipMemcpy(eng->view.overlay_count[i] + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(eng->view.path_count + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+    eng->path_n[e] = 0;
+    return SSMAP_OK;
+}
+
+int ssmap_path_append(ssmap_engine *eng, int32_t e, const int32_t *cells, int32_t n, void *stream_v) {
+    if (!eng || e < 0 || e >= eng->cfg.n_envs || n < 0 || (n > 0 && !cells))
+        return fail(SSMAP_ERR_INVALID_ARG, "bad env index or cell list");
+    if (!eng->envs[e].bound) return fail(SSMAP_ERR_NOT_READY, "the env has no maps bound (ssmap_bind_env)");
+    if (n == 0) return SSMAP_OK;
+    const ssmap_env_maps &mp = eng->envs[e].maps;
+    const int64_t n_cells = (int64_t)mp.map_h * mp.map_w;
+    for (int i = 0; i < n; ++i)
+        if (cells[i] < 0 || cells[i] >= n_cells) return fail(SSMAP_ERR_INVALID_ARG, "path cell outside the map");
+    if ((int64_t)eng->path_n[e] + n > eng->view.path_cap)
+        return fail(SSMAP_ERR_INVALID_ARG, "more path cells than the map has cells (append only new cells)");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipMemcpyAsync(eng->view.path_cells + (int64_t)e * eng->view.path_cap + eng->path_n[e], cells,
+                           sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
+    eng->path_n[e] += (uint32_t)n;
+    HIP_TRY(hipMemcpyAsync(eng->view.path_count + e, &eng->path_n[e], sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    // both sources are pageable host memory the caller or a later append may change: finish the copies
+    HIP_TRY(hipStreamSynchronize(stream));
+    return SSMAP_OK;
+}
+
+int ssmap_path_paint(ssmap_engine *eng, void *stream_v) {
+    if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    if (!eng->have_palette) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_palette was not called");
+    uint32_t most = 0;
+    for (uint32_t c : eng->path_n) most = std::max(most, c);
+    launch_path_paint(eng->view, most, reinterpret_cast<hipStream_t>(stream_v));
+    HIP_TRY(hipGetLastError());
     return SSMAP_OK;
 }
 

@@ -498,6 +498,26 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
     hipLaunchKernelGGL(k_label, grid, block, 0, s, v, f.semantic, f.semantic_unc, f.semantic_max_prob, f.semantic_gt);
 }
 
+// Path overlay (mapper.py:831-833): every cell of the trail shows the path id.
+__global__ void k_path_paint(View v) {
+    const int e = blockIdx.y;
+    const unsigned n = v.path_count[e];
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const int32_t *cells = v.path_cells + (int64_t)e * v.path_cap;
+    const int id = v.n_schema + 1;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cell = cells[i];
+        mp.semantic_map[cell] = (uint32_t)id;
+        paint(mp, v.palette, cell, id);
+    }
+}
+
+void launch_path_paint(const View &v, uint32_t max_count, hipStream_t s) {
+    if (max_count == 0) return;
+    const unsigned blocks = (max_count + 255u) / 256u;
+    hipLaunchKernelGGL(k_path_paint, dim3(blocks < 64u ? blocks : 64u, v.E), dim3(256), 0, s, v);
+}
+
 void launch_found(const View &v, hipStream_t s) {
     hipLaunchKernelGGL(k_found, dim3(kFoundBlocks, v.E), dim3(kFoundThreads), 0, s, v);
 }

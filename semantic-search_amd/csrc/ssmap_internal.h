@@ -130,6 +130,9 @@ struct View {
     const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
     const int32_t *pool_count; // [6]
     int32_t pool_trivial;      // no goal id pools more than one class
+    int32_t *path_cells;       // [E][path_cap] cells of the agent's trail (path overlay)
+    uint32_t *path_count;      // [E]
+    int64_t path_cap;          // max_map_h * max_map_w
     const NbModel *nb;         // [6] by goal id - 3 (stubborn rule)
     const float *nb_probs;     // [E][C][N] class probabilities of this step for the goal statistics
     const uint8_t *palette;    // [n][3]
@@ -195,6 +198,7 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_found(const View &v, hipStream_t s);
+void launch_path_paint(const View &v, uint32_t max_count, hipStream_t s);
 void launch_ego_maps(const View &v, const EgoPose *host_poses, const EgoTables *d_tables, const EgoTables &h_tables,
                      uint8_t *ego_small, uint8_t *ego_large, float *unc_small, float *unc_large, hipStream_t s);
 

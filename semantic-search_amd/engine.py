@@ -228,6 +228,21 @@ class MapEngine:
                                                   ids.ctypes.data, cnt.ctypes.data))
         self.schema_lut = lut
 
+    # ---- path overlay (mapper.py:822-833)
+    def path_append(self, e: int, cells):
+        """Adds cells (flat map indices, host ints) to env e's trail; reset_env empties it."""
+        cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int32).reshape(-1))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _capi.check(self.lib.ssmap_path_append(self._h, int(e), cells.ctypes.data, int(cells.shape[0]),
+                                                   C.c_void_p(stream)))
+
+    def path_paint(self):
+        """Stamps every env's trail into semantic_map / semantic_map_color (after `step`)."""
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _capi.check(self.lib.ssmap_path_paint(self._h, C.c_void_p(stream)))
+
     # ---- naive-Bayes models of the stubborn rule (mapper.py:184-191, 502-515)
     def set_nb_model(self, goal_sem_id: int, model):
         """`model`: a fitted sklearn GaussianNB, or any object / dict with its `classes_`,

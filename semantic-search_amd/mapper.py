@@ -8,7 +8,8 @@ fused there, and the map arrays are copied back only when a caller reads them.
 
 The "stubborn" rule takes its naive-Bayes models as fitted arrays (`nb_models`, or a JSON file
 written by tools/export_nb_models.py) instead of the reference's pickle (mapper.py:184-191).
-Not built yet: the path overlay (mapper.py:822-833).
+The path overlay (mapper.py:822-833) draws its line with cv2.line when OpenCV is importable and
+with an approximate thick line otherwise (`_line_cells`).
 """
 from __future__ import annotations
 
@@ -79,6 +80,44 @@ def fp_fn_detections(semantic_map, gt_map, goal_sem_id, centers, sizes, lower, p
     fp_mask = _dilate_box(pred & ~counted, int(0.1 / pixel2meter))
     _, fp = scipy.ndimage.label(fp_mask, scipy.ndimage.generate_binary_structure(2, 2))
     return int(fp), fn, is_fn
+
+
+def _draw_line(mask, p0, p1, color, thickness):
+    """cv2.line(mask, p0, p1, color, thickness) (mapper.py:823-830); points are (x, y).  Without
+    OpenCV: the 8-connected centre line of OpenCV's LineIterator under a square brush of
+    `thickness` cells, an approximation of the rectangle-plus-round-caps OpenCV fills."""
+    try:
+        import cv2
+    except ImportError:
+        return _line_cells(mask, p0, p1, color, thickness)
+    return cv2.line(mask, (int(p0[0]), int(p0[1])), (int(p1[0]), int(p1[1])), color, thickness)
+
+
+def _line_cells(mask, p0, p1, color, thickness):
+    x0, y0, x1, y1 = int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1])
+    if x1 < x0:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, abs(y1 - y0)
+    ystep = -1 if y1 < y0 else 1
+    steep = dy > dx
+    major, minor = (dy, dx) if steep else (dx, dy)
+    err, plus, minus = major - 2 * minor, 2 * major, -2 * minor
+    x, y = x0, y0
+    lo, hi = -((max(thickness, 1) - 1) // 2), max(thickness, 1) // 2
+    h, w = mask.shape[:2]
+    for _ in range(major + 1):
+        r0, r1, c0, c1 = max(y + lo, 0), min(y + hi, h - 1), max(x + lo, 0), min(x + hi, w - 1)
+        if r0 <= r1 and c0 <= c1:
+            mask[r0:r1 + 1, c0:c1 + 1] = color
+        bump = err < 0
+        err += minus + (plus if bump else 0)
+        if steep:
+            y += ystep
+            x += 1 if bump else 0
+        else:
+            x += 1
+            y += ystep if bump else 0
+    return mask
 
 
 def _load_nb_models(nb_models, model_name):
@@ -242,6 +281,7 @@ class SemanticMapper:
         self._host_cache = {}
         self.prev_pos_px = None
         self.found_idx = None
+        self.path_mask = np.zeros(_engine.map_size(self.map_bounds, self.pixel2meter), dtype=np.uint8)
         if self._engine is not None:
             rows, cols = _engine.map_size(self.map_bounds, self.pixel2meter)
             if rows <= self._engine.max_map_hw[0] and cols <= self._engine.max_map_hw[1]:
@@ -287,10 +327,20 @@ class SemanticMapper:
         if self.collect_nb_data and self.probablistic_mapping and self._rule in ("argmax", "stubborn"):
             self._collect_nb_rows(eng, goal_id)
         lower = self.map_bounds[:3]
-        self.prev_pos_px = self.world2map(np.asarray(obs["agent_position_and_rotation"])[:3], lower)
+        robot_pos_px = self.world2map(np.asarray(obs["agent_position_and_rotation"])[:3], lower)
         is_found = True if found[0] else None
         if is_found:
-            self.found_idx = self._disk_indices(self.prev_pos_px)
+            self.found_idx = self._disk_indices(robot_pos_px)
+        # path overlay, after the found decision (mapper.py:822-839)
+        if self.prev_pos_px is not None:
+            before = self.path_mask.astype(bool)
+            self.path_mask = _draw_line(self.path_mask, (self.prev_pos_px[1], self.prev_pos_px[0]),
+                                        (robot_pos_px[1], robot_pos_px[0]), 1, self.path_width_px)
+            new = np.flatnonzero(self.path_mask.astype(bool) & ~before)
+            if new.size:
+                eng.path_append(0, new)
+            eng.path_paint()
+        self.prev_pos_px = robot_pos_px
         small, large, unc_s, unc_l = eng.ego_maps(np.asarray(obs["agent_position_and_rotation"])[None], [goal_id],
                                                   None if auxillary_angle is None else np.asarray(auxillary_angle)[None])
         ego = (small[0].cpu().numpy(), large[0].cpu().numpy(),

@@ -17,8 +17,9 @@ behaviour of the pinned library version (reference `environment.yaml`):
 
 Parity at these seams is therefore UNPINNED by the golden vectors: they record the
 reference's own code running on top of these restatements.  `cv2.line`,
-`warpAffine`, `resize` and `getRotationMatrix2D` are inert (no path overlay, blank
-ego maps) because their rasterisation cannot be restated reliably from memory.
+`warpAffine`, `resize` and `getRotationMatrix2D` are inert (blank ego maps) because their
+rasterisation cannot be restated reliably from memory; `cv2.line` draws an approximate thick
+line (see `line` below), so the path overlay of mapper.py:822-833 takes part in the fixtures.
 """
 from __future__ import annotations
 
@@ -161,6 +162,17 @@ def circle(img, center, radius, color, thickness=1, *a, **k):
     return img
 
 
+def line(img, p0, p1, color, thickness=1, *a, **k):
+    """Stand-in for cv2.line: centre line of OpenCV's LineIterator under a square brush of
+    `thickness` cells (oracle/raster.py line_cells).  OpenCV's thick-line polygon is NOT restated:
+    the fixtures pin how the mapper uses the path mask, not the raster of the line itself."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import raster
+    return raster.line(img, p0, p1, color, thickness)
+
+
 def erode(src, kernel, iterations=1, **k):
     assert iterations == 1
     kh, kw = kernel.shape
@@ -201,7 +213,7 @@ def _make_cv2():
     m.erode = erode
     m.dilate = dilate
     m.getStructuringElement = lambda shape, ksize: np.ones((ksize[1], ksize[0]), dtype=np.uint8)
-    m.line = lambda img, p0, p1, color, thickness=1, *a, **k: img
+    m.line = line
     m.getRotationMatrix2D = lambda c, ang, s: np.zeros((2, 3))
     m.warpAffine = lambda src, M, dsize, **k: np.zeros_like(src)
     m.resize = lambda src, dsize, **k: np.zeros(

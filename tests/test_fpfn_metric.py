@@ -69,3 +69,19 @@ def test_mapper_method_on_device_maps(name):
     boxes = [types.SimpleNamespace(center=ce, sizes=sz) for ce, sz in zip(c["centers"], c["sizes"])]
     fp, fn, is_fn = m.compute_fp_fn_detections(np.array([int(GOLD[f"{name}_goal_index"])]), boxes)
     assert (fp, fn, list(is_fn)) == c["want"]
+
+
+def test_mapper_line_fallback_equals_the_oracle_raster():
+    """The mapper's own thick-line fallback (used when OpenCV is absent) and the raster the
+    fixtures were recorded with are the same function of (p0, p1, thickness)."""
+    import importlib
+    mapper_mod = importlib.import_module("semantic_search_amd.mapper")
+    from oracle import raster
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        p0 = tuple(int(v) for v in rng.integers(-5, 45, 2))
+        p1 = tuple(int(v) for v in rng.integers(-5, 45, 2))
+        t = int(rng.integers(1, 5))
+        a = mapper_mod._line_cells(np.zeros((40, 40), np.uint8), p0, p1, 1, t)
+        b = raster.line(np.zeros((40, 40), np.uint8), p0, p1, 1, t)
+        assert np.array_equal(a, b), (p0, p1, t)

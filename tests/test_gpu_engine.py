@@ -75,7 +75,7 @@ def _run_pair(rule, n_classes, temperature, n_frames, hw, from_logits, attrs=Non
     lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate=rule, seg_model_n_classes=n_classes, filter_goal_prob=filter_goal_prob)
-    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
     eng = ssa.MapEngine(1, hw, max_map_hw=ssa.map_size(bounds, 0.03), **kw)
     eng.set_schema(lut)
     for k, v in (attrs or {}).items():
@@ -165,7 +165,7 @@ def test_far_depths_take_the_unbinned_winner_path():
     bounds = np.array([0.0, 0.0, 0.0, 28.79, 3.0, 28.79])
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 40.0), probablistic_mapping=True,
               prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
-    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
     eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(bounds, 0.03), **kw)
     eng.set_schema(lut)
     ref.reset(bounds)
@@ -221,7 +221,7 @@ def test_depths_beyond_depth_max_leave_the_predicted_box():
     lut = scenes.small_lut(c)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
-    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
     eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
     eng.set_schema(lut)
     ref.reset(BOUNDS_480)
@@ -249,7 +249,7 @@ def test_frame_of_more_than_a_million_pixels():
     lut = scenes.small_lut(c)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
-    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
     eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
     eng.set_schema(lut)
     ref.reset(BOUNDS_480)
@@ -326,7 +326,7 @@ def test_full_size_label_rules_from_logits(rule, attrs, filt):
     lut = scenes.schema_lut(c)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate=rule, seg_model_n_classes=c, filter_goal_prob=filt)
-    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
     eng = ssa.MapEngine(1, (h, w), max_map_hw=(480, 480), **kw)
     eng.set_schema(lut)
     for k, v in attrs.items():
@@ -422,7 +422,7 @@ def test_index_below_minus_dim_is_reported_like_numpy():
     agent, cam = scenes.make_pose(1.0, 0.0, 1.0, np.pi + 0.75)
     frame = scenes.room_frame(np.random.default_rng(0), h, w, 0, 1.0, cam)
     obs = scenes.make_obs(frame, agent, cam)
-    ref = mo.OracleMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    ref = mo.OracleMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), path_overlay=False)
     ref.reset(np.array([4.0, 0.0, 4.0, 4.6, 2.5, 4.6]))
     with pytest.raises(IndexError):
         ref.update(scenes.make_obs(frame, agent, cam))

@@ -7,8 +7,9 @@
 //   * in registers when C is one of the compiled sizes (kernel k_stream_reg), or
 //   * in a private LDS column of stride 257 floats otherwise (kernel k_stream_lds).
 // Pixels that own a map cell this step (wflag[pix] set by the winner kernel, target[pix] = their
-// slot in the frame's update list) hand their probability vector, staged through LDS, to row
-// `slot` of a compact [K][C] buffer; the streaming pass never waits on map memory.
+// slot in the frame's update list) write their probability vector to row `slot` of a compact
+// [K][C] buffer (vector stores under the owners' execution mask; staging the rows through LDS
+// for fully coalesced writes measured the same); the streaming pass never waits on map memory.
 // k_update_prob then gives every update cell to a 16-lane row of a wave, lanes over the classes:
 // the read-modify-write of the cell's C contiguous floats in the fused map is coalesced and the
 // per-cell entropy / argmax are DPP row reductions.
@@ -53,18 +54,6 @@ struct StreamArgs {
 };
 
 // ---------------------------------------------------------------- register kernel
-// Winner rows leave the block through LDS: the few pixels of a block that own a map cell park
-// their C probabilities in a staging row, then all threads write the staged rows to the
-// compact buffer with consecutive lanes on consecutive addresses (a winner writing its own
-// row would issue C stores of 4 scattered bytes per lane).
-template <int CT>
-struct Stage {
-    static constexpr int kRows = CT > 64 ? 32 : 64;
-    float row[kRows][CT];
-    int slot[kRows];
-    int count;
-};
-
 // One pixel per thread.  The C class planes of the env's frame are read through one buffer
 // descriptor: lane offset (pixel) in a vector register, plane offset in a scalar register, so
 // the C loads need no per-lane 64-bit address arithmetic.  Loads are nontemporal: the frame is
@@ -73,7 +62,6 @@ struct Stage {
 // wider requests gain.)
 template <int CT, int MODE>
 __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
-    __shared__ Stage<CT> stage;
     const int e = blockIdx.y;
     const int t = threadIdx.x;
     const int pix = blockIdx.x * kTile + t;
@@ -145,37 +133,17 @@ __global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
     }
     if (MODE == 0) return;
 
-    if (t == 0) stage.count = 0;
-    __syncthreads();
-    const int place = slot >= 0 ? atomicAdd(&stage.count, 1) : -1;
-    __syncthreads();
-    const int total = stage.count;
-    constexpr int kRows = Stage<CT>::kRows;
-    for (int r0 = 0; r0 < total; r0 += kRows) {
-        const int k = place - r0;
-        if (place >= 0 && k >= 0 && k < kRows) {
-            stage.slot[k] = slot;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) stage.row[k][c] = x[c];
-        }
-        __syncthreads();
-        const int rows = min(kRows, total - r0);
+    // an owner writes its own row: CT / 4 vector stores under the owners' execution mask
+    if (slot >= 0) {
+        float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
         if (CT % 4 == 0) {
-            constexpr int Q = CT / 4;
-            const int qs = v.wprob_stride / 4;     // rows may be padded to whole cache lines
-            for (int j = t; j < rows * qs; j += kTile) {
-                const int k = j / qs, q = j - k * qs;
-                float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (q < Q) val = *reinterpret_cast<const float4 *>(&stage.row[k][4 * q]);
-                *reinterpret_cast<float4 *>(v.wprob + (fbase + stage.slot[k]) * v.wprob_stride + 4 * q) = val;
-            }
+#pragma unroll
+            for (int q = 0; q < CT / 4; ++q)
+                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
         } else {
-            for (int j = t; j < rows * CT; j += kTile) {
-                const int k = j / CT, c = j - k * CT;
-                v.wprob[(fbase + stage.slot[k]) * v.wprob_stride + c] = stage.row[k][c];
-            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) dst[c] = x[c];
         }
-        __syncthreads();
     }
 }
 

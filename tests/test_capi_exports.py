@@ -62,3 +62,13 @@ def test_create_rejects_configs_before_touching_the_gpu():
         assert rc != 0 and not handle.value, bad
         assert text in lib.ssmap_last_error().decode(), (bad, lib.ssmap_last_error())
     assert ctypes.sizeof(c.EgomapConfig) == 8 * 4 + 2 * c.MAX_AUX * 4 + 8
+
+
+def test_late_entry_points_reject_null_arguments_without_a_gpu():
+    """ssmap_set_nb_model / ssmap_path_append / ssmap_path_paint check their arguments first."""
+    import semantic_search_amd as ssa
+    lib = ssa._capi.load()
+    assert lib.ssmap_set_nb_model(None, 3, 2, None, None, None, None, None) == 1
+    assert lib.ssmap_path_append(None, 0, None, 0, None) == 1
+    assert lib.ssmap_path_paint(None, None) == 1
+    assert "null" in lib.ssmap_last_error().decode()

@@ -25,6 +25,8 @@ struct EgoView {
     const EgoTables *tab;       // global; only its scalars are read per tap
     const int32_t *aux_points;  // LDS copy of tab->aux_points
     const int32_t *agent_hw;    // LDS copy of tab->agent_hw
+    const uint8_t *palette;     // LDS copy of the first n_palette palette rows
+    int n_palette;
     bool has_aux;
     int side, origin, aux_half, aux_reach, n_aux, agent_radius;
 };
@@ -77,8 +79,14 @@ __device__ inline void rot_pixel(const EgoView &ev, int X, int Y, int x0, int y0
     bool in_map;
     rgb[0] = rgb[1] = rgb[2] = 0;
     if (!warp_cell(ev, x0, y0, ad, bd, cell, in_map) || !in_map) return;
-    if ((int)ev.mp->semantic_map[cell] == ev.pose->goal_id) {               // mapper.py:920
+    const int id = (int)ev.mp->semantic_map[cell];
+    if (id == ev.pose->goal_id) {                                           // mapper.py:920
         rgb[0] = t.active_goal_color[0]; rgb[1] = t.active_goal_color[1]; rgb[2] = t.active_goal_color[2];
+    } else if (id < ev.n_palette) {
+        // semantic_map_color[cell] is palette[semantic_map[cell]] after every write of the mapper
+        // (mapper.py:728-733, 772, 833): one gather instead of four
+        const uint8_t *c = ev.palette + 3 * id;
+        rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
     } else {
         const uint8_t *c = ev.mp->semantic_map_color + 3ll * cell;
         rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
@@ -102,9 +110,12 @@ __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0
     __shared__ EgoPose s_pose;
     __shared__ int32_t s_aux[2 * SSMAP_MAX_AUX];
     __shared__ int32_t s_hw[kEgoMaxRadius + 1];
+    __shared__ uint8_t s_pal[3 * 64];
     if (threadIdx.x == 0) s_pose = pack.p[blockIdx.z];
     if (threadIdx.x < 2 * SSMAP_MAX_AUX) s_aux[threadIdx.x] = t.aux_points[threadIdx.x];
     if (threadIdx.x <= kEgoMaxRadius) s_hw[threadIdx.x] = t.agent_hw[threadIdx.x];
+    const int n_pal = min(v.palette_rows, 64);
+    if (threadIdx.x < 3 * n_pal) s_pal[threadIdx.x] = v.palette[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= t.out_w * t.out_h) return;
@@ -116,6 +127,8 @@ __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0
     ev.tab = tables;
     ev.aux_points = s_aux;
     ev.agent_hw = s_hw;
+    ev.palette = s_pal;
+    ev.n_palette = n_pal;
     ev.has_aux = s_pose.has_aux != 0;
     ev.side = t.side;
     ev.origin = t.origin;

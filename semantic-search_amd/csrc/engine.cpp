@@ -314,6 +314,7 @@ int ssmap_set_palette(ssmap_engine *eng, const uint8_t *rgb, int32_t n) {
     if (rc != SSMAP_OK) return rc;
     HIP_TRY(hipMemcpy(eng->d_palette, rgb, 3 * n, hipMemcpyHostToDevice));
     eng->view.palette = eng->d_palette;
+    eng->view.palette_rows = n;
     eng->palette_rows = n;
     eng->have_palette = true;
     return SSMAP_OK;
@@ -533,6 +534,7 @@ int ssmap_ego_maps(ssmap_engine *eng, const double *agent_pose, const int32_t *g
     if (!eng || !agent_pose || !goal_sem_id || !ego_small || !ego_large)
         return fail(SSMAP_ERR_INVALID_ARG, "agent_pose, goal_sem_id, ego_small and ego_large are required");
     if (eng->h_ego.empty()) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_egomap was not called");
+    if (!eng->have_palette) return fail(SSMAP_ERR_NOT_READY, "ssmap_set_palette was not called");
     for (const EnvState &s : eng->envs)
         if (!s.bound) return fail(SSMAP_ERR_NOT_READY, "an env has no maps bound (ssmap_bind_env)");
     const ssmap_config &c = eng->cfg;

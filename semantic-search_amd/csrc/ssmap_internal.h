@@ -135,7 +135,8 @@ struct View {
     int64_t path_cap;          // max_map_h * max_map_w
     const NbModel *nb;         // [6] by goal id - 3 (stubborn rule)
     const float *nb_probs;     // [E][C][N] class probabilities of this step for the goal statistics
-    const uint8_t *palette;    // [n][3]
+    const uint8_t *palette;    // [palette_rows][3]
+    int32_t palette_rows;
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;
     ssmap_params prm;

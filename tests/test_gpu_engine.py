@@ -413,6 +413,58 @@ def test_batched_engine_equals_independent_engines(n_envs):
         s.close()
 
 
+def test_benchmark_configuration_replicated_envs_agree():
+    """BASELINE configs[1] at full size (height_map_log_odds, 16 envs, 640x480, 40 classes, logits
+    in): envs fed the same frame and pose must end bit-identical, a one-env engine fed that frame
+    must equal them, and envs fed another frame must differ."""
+    import semantic_search_amd as ssa
+    h, w, c, temp, E = 480, 640, 40, 3.2, 16
+    lut = scenes.schema_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_log_odds", seg_model_n_classes=c)
+    big = ssa.MapEngine(E, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
+    one = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(BOUNDS_480, 0.03), **kw)
+    for eng in (big, one):
+        eng.set_schema(lut)
+        eng.params.entropy_threshold = 0.0171
+    for e in range(E):
+        big.reset_env(e, BOUNDS_480)
+    one.reset_env(0, BOUNDS_480)
+    rng, prng = np.random.default_rng(61), np.random.default_rng(62)
+    for i in range(2):
+        fa = scenes.uniform_frame(rng, h, w, c, temp, lut=lut, with_probs=False)
+        fb = scenes.uniform_frame(rng, h, w, c, temp, lut=lut, with_probs=False)
+        pa = scenes.make_pose(7.2, 0.0, 7.2, prng.uniform(0, 2 * np.pi))
+        pb = scenes.make_pose(7.0, 0.0, 7.4, prng.uniform(0, 2 * np.pi))
+        pick = [fa if e < 8 else fb for e in range(E)]
+        pose = [pa if e < 8 else pb for e in range(E)]
+        depth = _to_dev(np.stack([f["depth"] for f in pick]), np.float32)
+        logits = _to_dev(np.stack([f["logits"] for f in pick]), np.float32)
+        gt = _to_dev(np.stack([f["semantic_gt"] for f in pick]), np.int32)
+        sem = torch.empty((E, h, w), dtype=torch.int32, device="cuda")
+        unc = torch.empty((E, h, w), dtype=torch.float32, device="cuda")
+        maxp = torch.empty((E, h, w), dtype=torch.float32, device="cuda")
+        big.step(depth, np.stack([p[0] for p in pose]), np.stack([p[1] for p in pose]), [3] * E, logits=logits,
+                 temperature=temp, semantic=sem, semantic_unc=unc, semantic_max_prob=maxp, semantic_gt=gt)
+        one.step(depth[:1].clone(), pa[0][None], pa[1][None], [3], logits=logits[:1].contiguous(), temperature=temp,
+                 semantic=sem[:1].clone(), semantic_unc=unc[:1].clone(), semantic_max_prob=maxp[:1].clone(),
+                 semantic_gt=gt[:1].contiguous())
+        found, status, n_upd = big.results()
+        assert not status.any()
+        assert len(set(n_upd[:8].tolist())) == 1 and len(set(n_upd[8:].tolist())) == 1
+        assert n_upd[0] == one.results()[2][0]
+        assert torch.equal(sem[0], sem[7]) and torch.equal(unc[8], unc[15])
+    for nm, t in big.maps[0].items():
+        for e in range(1, 8):
+            assert torch.equal(t, big.maps[e][nm]), (e, nm)
+        assert torch.equal(t, one.maps[0][nm]), nm
+        for e in range(9, 16):
+            assert torch.equal(big.maps[8][nm], big.maps[e][nm]), (e, nm)
+    assert not torch.equal(big.maps[0]["semantic_map"], big.maps[8]["semantic_map"])
+    big.close()
+    one.close()
+
+
 def test_index_below_minus_dim_is_reported_like_numpy():
     """A selected cell with index < -dim makes the reference raise IndexError (mapper.py:338)."""
     import semantic_search_amd as ssa

@@ -109,3 +109,56 @@ def test_random_scenario_matches_oracle(seed):
         top2 = np.sort(getattr(ref, name)[bad], axis=-1)[:, -2:]
         assert (np.abs(top2[:, 1] - top2[:, 0]) <= 1e-4 * np.maximum(1.0, np.abs(top2[:, 1]))).all()
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scenario_label_rules(seed):
+    """The same scenario generator for the label rules that have exact wrap semantics (argmax with
+    and without the goal filter, goal_decay, direct mapping): every integer map bit-exact."""
+    import semantic_search_amd as ssa
+    sc = _scenario(100 + seed)
+    rng, (h, w), c = sc["rng"], sc["hw"], sc["c"]
+    lut = scenes.small_lut(c)
+    rule, prob, filt = [("height_map_argmax", True, None), ("height_map_argmax", True, 0.4),
+                        ("height_map_goal_decay", True, 0.35), ("height_map_argmax", False, None)][seed % 4]
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=prob,
+              prob_aggregate=rule, seg_model_n_classes=c, filter_goal_prob=filt)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(sc["bounds"], 0.03), **kw)
+    eng.set_schema(lut)
+    ref.reset(sc["bounds"])
+    maps = eng.reset_env(0, sc["bounds"])
+    for i in range(3):
+        frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
+        frame["depth"] = _depth(sc, rng)
+        agent, cam = scenes.make_pose(sc["agent"][0] + 0.2 * i, sc["floor"], sc["agent"][1], rng.uniform(0, 2 * np.pi),
+                                      pitch=sc["pitch"])
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs["depth"] = frame["depth"].copy()
+        raised = False
+        try:
+            found_ref = ref.update(obs)
+        except IndexError:
+            raised = True
+        extra = {}
+        if prob:
+            extra = dict(semantic_unc=_dev(frame["semantic_unc"][None], np.float32),
+                         semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
+                         semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
+        eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 semantic=_dev(frame["semantic"][None], np.int32), **extra)
+        found, status, n_upd = eng.results()
+        if raised or status[0]:
+            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+            eng.close()
+            return
+        assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
+        assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map), f"frame {i} ({rule})"
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["semantic_map_color"].cpu().numpy(), ref.semantic_map_color)
+    if prob:
+        assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
+        assert np.array_equal(maps["unc_map"].cpu().numpy(), ref.unc_map)
+    if "goal_decay" in rule:
+        assert np.array_equal(maps["goal_map"].cpu().numpy(), ref.goal_map)
+    eng.close()

@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
             hits = mp.hits[cell];
             bg = (int)mp.background_map[cell];
         }
+        const float views_old = views, hits_old = hits;
+        const int bg_old = bg;
         // height map (mapper.py:338-341)
         const float h = fmaxf(h_old, (float)(unorder_f64(hk) - pb.agent[1]));
         mp.height_map[cell] = h;
@@ -174,24 +176,56 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
         if (hv) {
             const bool weighted = v.rule == SSMAP_RULE_PROB_HV;
             if (weighted) mp.unc_map[cell] = unc_v;
-            else if (v.prm.use_filter && id == goal && maxp_v < v.prm.filter_goal_prob) id = 0;
-            id = occupancy_override(id, h, v.use_height, v.n_schema);
-            if (id != goal) { mp.background_map[cell] = (uint32_t)id; bg = id; }
-
-            bool gated = true;
-            if (v.prm.hv_limit_obj_view_dist > 0.0) {
-                // map2world of the UNWRAPPED cell (mapper.py:639-644, 865-874)
-                int row = cell / mp.map_w, col = cell - row * mp.map_w;
-                if (pw & kRowNegBit) row -= mp.map_h;
-                if (pw & kColNegBit) col -= mp.map_w;
-                const double dx = ((double)col * v.p2m + mp.lower[0]) - pb.agent[0];
-                const double dz = ((double)row * v.p2m + mp.lower[2]) - pb.agent[2];
-                gated = sqrt(dx * dx + dz * dz) < v.prm.hv_limit_obj_view_dist;
+            // Up to four update pixels can share a cell through numpy's negative-index wrap, one
+            // per sign quadrant (k_resolve_wrapped recorded them; this thread has the highest
+            // pixel, the others were dropped from the list).  numpy applies every statement of
+            // the rule to all of them with "the last one wins" among the entries that statement
+            // selects, so the pixels are walked in ascending order and each statement keeps the
+            // last value it saw (mapper.py:630-666, 689-727).
+            int others[3], other_quad[3], n_others = 0;
+            if (hdr->n_neg) {
+                const int4 qs = *reinterpret_cast<const int4 *>(v.quad + e * v.quad_stride + 4ll * cell);
+                const int q4[4] = {qs.x, qs.y, qs.z, qs.w};
+                for (int q = 0; q < 4; ++q)
+                    if (q4[q] != 0 && q4[q] != pix + 1) {
+                        int at = n_others++;
+                        while (at > 0 && others[at - 1] > q4[q] - 1) {   // ascending pixel order
+                            others[at] = others[at - 1]; other_quad[at] = other_quad[at - 1]; --at;
+                        }
+                        others[at] = q4[q] - 1; other_quad[at] = q;
+                    }
             }
-            const float add = weighted ? maxp_v : 1.0f;
-            if (!weighted || gated) { views += add; mp.views[cell] = views; }
-            if (gated && raw == goal) { hits += add; mp.hits[cell] = hits; }
-            const bool show = gated && hits > 0.0f && views != INFINITY;
+            bool any_gated = false;
+            for (int k = 0; k <= n_others; ++k) {
+                const bool self = k == n_others;                      // this thread's pixel comes last
+                const int p = self ? pix : others[k];
+                const int raw_k = self ? raw : semantic[fbase + p];
+                const float maxp_k = self ? maxp_v : (maxp ? maxp[fbase + p] : 0.0f);
+                const bool row_neg = self ? (pw & kRowNegBit) != 0 : (other_quad[k] & 2) != 0;
+                const bool col_neg = self ? (pw & kColNegBit) != 0 : (other_quad[k] & 1) != 0;
+                int id_k = raw_k;
+                if (!weighted && v.prm.use_filter && id_k == goal && maxp_k < v.prm.filter_goal_prob) id_k = 0;
+                id_k = occupancy_override(id_k, h, v.use_height, v.n_schema);
+                if (id_k != goal) bg = id_k;
+                bool gated = true;
+                if (v.prm.hv_limit_obj_view_dist > 0.0) {
+                    // map2world of the UNWRAPPED cell (mapper.py:639-644, 865-874)
+                    int row = cell / mp.map_w, col = cell - row * mp.map_w;
+                    if (row_neg) row -= mp.map_h;
+                    if (col_neg) col -= mp.map_w;
+                    const double dx = ((double)col * v.p2m + mp.lower[0]) - pb.agent[0];
+                    const double dz = ((double)row * v.p2m + mp.lower[2]) - pb.agent[2];
+                    gated = sqrt(dx * dx + dz * dz) < v.prm.hv_limit_obj_view_dist;
+                }
+                const float add = weighted ? maxp_k : 1.0f;
+                if (!weighted || gated) views = views_old + add;      // buffered +=: from the old value
+                if (gated && raw_k == goal) hits = hits_old + add;
+                any_gated |= gated;
+            }
+            if (bg != bg_old) mp.background_map[cell] = (uint32_t)bg;
+            if (views != views_old) mp.views[cell] = views;
+            if (hits != hits_old) mp.hits[cell] = hits;
+            const bool show = any_gated && hits > 0.0f && views != INFINITY;
             const int shown = show ? goal : bg;
             mp.semantic_map[cell] = (uint32_t)shown;
             paint(mp, v.palette, cell, shown);

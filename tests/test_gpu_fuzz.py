@@ -162,3 +162,56 @@ def test_random_scenario_label_rules(seed):
     if "goal_decay" in rule:
         assert np.array_equal(maps["goal_map"].cpu().numpy(), ref.goal_map)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenario_hit_view_rules(seed):
+    """height_map_hv / height_map_prob_hv: background, hits, views and labels bit-exact, including
+    update pixels that share a cell through the negative-index wrap (numpy applies every statement
+    of the rule with its own 'last write wins')."""
+    import semantic_search_amd as ssa
+    sc = _scenario(200 + seed)
+    rng, (h, w), c = sc["rng"], sc["hw"], sc["c"]
+    lut = scenes.small_lut(c)
+    rule = ["height_map_hv", "height_map_prob_hv"][seed % 2]
+    filt = 0.4 if (rule == "height_map_hv" and seed % 3 == 0) else None
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=c, filter_goal_prob=filt)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(sc["bounds"], 0.03), **kw)
+    for o in (ref, eng.params):
+        o.hv_min_views = 1
+        o.hv_ratio = 0.3
+        o.hv_limit_obj_view_dist = 3.0 if seed % 4 < 2 else 0.0
+    eng.set_schema(lut)
+    ref.reset(sc["bounds"])
+    maps = eng.reset_env(0, sc["bounds"])
+    for i in range(3):
+        frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
+        frame["depth"] = _depth(sc, rng)
+        agent, cam = scenes.make_pose(sc["agent"][0] + 0.2 * i, sc["floor"], sc["agent"][1], rng.uniform(0, 2 * np.pi),
+                                      pitch=sc["pitch"])
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs["depth"] = frame["depth"].copy()
+        raised = False
+        try:
+            found_ref = ref.update(obs)
+        except IndexError:
+            raised = True
+        eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 semantic=_dev(frame["semantic"][None], np.int32),
+                 semantic_unc=_dev(frame["semantic_unc"][None], np.float32),
+                 semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
+                 semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        if raised or status[0]:
+            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+            eng.close()
+            return
+        assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
+        for nm in ("semantic_map", "background_map"):
+            assert np.array_equal(maps[nm].cpu().numpy().view(np.uint32), getattr(ref, nm)), f"frame {i}: {nm}"
+        for nm in ("hits", "views", "height_map"):
+            assert np.array_equal(maps[nm].cpu().numpy(), getattr(ref, nm)), f"frame {i}: {nm}"
+    assert np.array_equal(maps["unc_map"].cpu().numpy(), ref.unc_map)
+    eng.close()

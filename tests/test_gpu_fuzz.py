@@ -215,3 +215,52 @@ def test_random_scenario_hit_view_rules(seed):
             assert np.array_equal(maps[nm].cpu().numpy(), getattr(ref, nm)), f"frame {i}: {nm}"
     assert np.array_equal(maps["unc_map"].cpu().numpy(), ref.unc_map)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenario_stubborn_rule(seed):
+    """height_map_stubborn under the random scenarios: labels and view counts bit-exact, the
+    float statistics within 1e-6 (sums of a few float32 probabilities in the same order)."""
+    import semantic_search_amd as ssa
+    from tests import golden_util as gu
+    sc = _scenario(300 + seed)
+    rng, (h, w), c = sc["rng"], sc["hw"], max(sc["c"], 5)
+    lut = scenes.small_lut(c)
+    model = gu.GoldenCase("stubborn_nb").mapper_kwargs()["nb_models"][3]
+    goal_classes = {3: [3, 4] if seed % 2 else [3]}
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_stubborn", seg_model_n_classes=c)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, nb_models={3: model}, objnav_to_sem_pred=goal_classes, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(sc["bounds"], 0.03), **kw)
+    eng.set_schema(lut, {g: goal_classes.get(g, []) for g in range(3, 9)})
+    eng.set_nb_model(3, model)
+    ref.reset(sc["bounds"])
+    maps = eng.reset_env(0, sc["bounds"])
+    for i in range(3):
+        frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
+        frame["depth"] = _depth(sc, rng)
+        agent, cam = scenes.make_pose(sc["agent"][0] + 0.2 * i, sc["floor"], sc["agent"][1], rng.uniform(0, 2 * np.pi),
+                                      pitch=sc["pitch"])
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs["depth"] = frame["depth"].copy()
+        raised = False
+        try:
+            ref.update(obs)
+        except IndexError:
+            raised = True
+        eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 probs=_dev(frame["semantic_prob"][None], np.float32),
+                 semantic=_dev(frame["semantic"][None], np.int32),
+                 semantic_unc=_dev(frame["semantic_unc"][None], np.float32),
+                 semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
+                 semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        if raised or status[0]:
+            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+            eng.close()
+            return
+        assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map), f"frame {i}"
+        assert np.array_equal(maps["total_view"].cpu().numpy().view(np.uint32), ref.total_view), f"frame {i}"
+    for nm in ("cumulative_conf", "max_conf", "max_other_conf"):
+        assert np.allclose(maps[nm].cpu().numpy(), getattr(ref, nm), rtol=1e-6, atol=1e-7), nm
+    eng.close()

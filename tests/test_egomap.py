@@ -148,3 +148,37 @@ def test_mapper_update_map_returns_ego_maps():
                       int(m.goal2sem_id[0]), m.color_pallete, aux_angle_onehot=np.eye(12, dtype=np.float32)[3])
     assert np.array_equal(small, want[0]) and np.array_equal(large, want[1])
     assert np.array_equal(unc_s, want[2]) and np.array_equal(unc_l, want[3])
+
+
+@pytest.mark.gpu
+def test_engine_ego_maps_more_envs_than_one_launch_takes():
+    """18 envs: the poses travel in packs of 16 per launch; every env still gets its own maps."""
+    import torch
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(12)
+    n = 18
+    bounds = [np.array([0.0, 0.0, 0.0, 6.0 + 0.3 * (e % 4), 2.5, 5.0 + 0.2 * (e % 5)]) for e in range(n)]
+    eng = ssa.MapEngine(n, (48, 64), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                        probablistic_mapping=True, prob_aggregate="height_map_argmax", max_map_hw=(240, 240))
+    eng.set_egomap()
+    palette = eng.color_pallete
+    host, poses, goals = [], [], []
+    for e in range(n):
+        maps = eng.reset_env(e, bounds[e])
+        rows, cols = maps["semantic_map"].shape
+        sem, color, unc = _random_maps(rng, rows, cols, palette, 3)
+        maps["semantic_map"].copy_(torch.from_numpy(sem.view(np.int32)))
+        maps["semantic_map_color"].copy_(torch.from_numpy(color))
+        maps["unc_map"].copy_(torch.from_numpy(unc))
+        host.append((sem, color, unc))
+        pos = np.array([rng.uniform(0.5, 5.5), 0.1, rng.uniform(0.5, 4.5)])
+        poses.append(np.concatenate([pos, _yaw_quat(rng.uniform(-math.pi, math.pi))]))
+        goals.append(3 + e % 6)
+    small, large, unc_s, unc_l = eng.ego_maps(np.stack(poses), goals, None)
+    torch.cuda.synchronize()
+    for e in (0, 7, 15, 16, 17):
+        sem, color, unc = host[e]
+        want = eo.ego_map(sem, color, unc, poses[e][:3], poses[e][3:], bounds[e][:3], goals[e], palette)
+        assert np.array_equal(small[e].cpu().numpy(), want[0]) and np.array_equal(large[e].cpu().numpy(), want[1]), e
+        assert np.array_equal(unc_s[e].cpu().numpy(), want[2]) and np.array_equal(unc_l[e].cpu().numpy(), want[3]), e
+    eng.close()

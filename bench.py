@@ -220,7 +220,7 @@ def main():
                 traffic = json.load(fh).get(args.workload, {}).get(f"E{E}", {}).get("k_stream_bytes_per_launch")
         except OSError:
             pass
-        names = ("geometry", "bin_and_winners", "stream_stage1", "rule_update", "found")
+        names = ("geometry", "winners", "stream_stage1", "rule_update", "found")
         line = {
             "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",
             "value": frames_total / elapsed,

@@ -122,6 +122,21 @@ def cpu_baseline(workload, n_frames, seed):
     return done / elapsed, done
 
 
+def _cpu_worker(job):
+    workload, n_frames, seed = job
+    return cpu_baseline(workload, n_frames, seed)
+
+
+def cpu_baseline_processes(workload, n_procs, n_frames):
+    """The reference's own scaling model on a CPU: one mapper per OS process (eval_objnav.py:144).
+    n_procs independent processes run the oracle at the same time; returns the summed frames/s.
+    Must run before this process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(n_procs) as pool:
+        res = pool.map(_cpu_worker, [(workload, n_frames, 100 + i) for i in range(n_procs)])
+    return sum(r[0] for r in res), sum(r[1] for r in res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +151,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_many = None
+    if world == 1 and not args.no_cpu_baseline:
+        # forked workers: before anything here initialises the GPU
+        n_procs = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
+        cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 10)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -251,7 +271,10 @@ def main():
             fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"{n_done} frames of the same workload (1 env, stage 1 on "
-                                              "torch CPU + numpy oracle), 1 thread"}
+                                              "torch CPU + numpy oracle), 1 thread",
+                                    "all_cores": {"value": cpu_many[1], "unit": "frames/s", "cores": cpu_many[0],
+                                                  "sample": f"{cpu_many[2]} frames over {cpu_many[0]} independent "
+                                                            "processes, one env each, run at the same time"}}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

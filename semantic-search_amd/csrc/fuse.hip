@@ -19,6 +19,7 @@
 namespace ssmap {
 
 constexpr int kTile = 256;
+constexpr int kRegTile = 256;      // block of the register kernel (64 and 1024 threads measured slower)
 constexpr int kStride = kTile + 1;
 
 // scipy.special.entr: -x log x, 0 at 0, -inf below 0
@@ -61,10 +62,10 @@ struct StreamArgs {
 // wider loads measured slower: the larger register footprint costs more occupancy than the
 // wider requests gain.)
 template <int CT, int MODE>
-__global__ __launch_bounds__(kTile) void k_stream_reg(View v, StreamArgs a) {
+__global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     const int e = blockIdx.y;
     const int t = threadIdx.x;
-    const int pix = blockIdx.x * kTile + t;
+    const int pix = blockIdx.x * kRegTile + t;
     const bool active = pix < v.N;
     const int64_t fbase = (int64_t)e * v.N;
     const int boff = active ? pix * 4 : 0;
@@ -392,10 +393,10 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
 
 template <int CT>
 static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
-    dim3 grid((v.N + kTile - 1) / kTile, v.E);
-    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kTile), 0, s, v, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kTile), 0, s, v, a);
-    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kTile), 0, s, v, a);
+    dim3 grid((v.N + kRegTile - 1) / kRegTile, v.E);
+    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kRegTile), 0, s, v, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kRegTile), 0, s, v, a);
+    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kRegTile), 0, s, v, a);
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {

@@ -157,20 +157,19 @@ __device__ inline PixelGeom pixel_geometry(const View &v, const PoseBlock &pb, c
     return g;
 }
 
-// Binning: the live pixels of a frame are sorted by winner table into contiguous arrays of
-// 12-byte records {height image, slot << 19 | pixel} so that a winner-table block reads only its
-// own records instead of every pixel of the frame.  The geometry kernel already counts its
-// pixels per table, so two small kernels remain: prefix sums (with the frame header) and scatter.
-// Record order inside a table is arbitrary (the table reductions are order independent).
+// Binning: every live pixel of a frame leaves a 12-byte record {height image, slot << 19 | pixel}
+// with the winner table of its cell, so that a winner-table block reads only its own records
+// instead of every pixel of the frame.  Record order inside a table is arbitrary (the table
+// reductions are order independent).
 //
 // Deal of cells to tables: runs of 8 cells of one map row ("chunks", numbered cc along the row
 // in absolute biased coordinates) go to table (cc + 3 row) mod 16.  The table of a cell thus does
-// not depend on the frame's cell box, which is why the geometry kernel can count before the box
-// is known; the skew by 3 per row spreads a wall seen edge-on over all tables.  Inside a table a
-// cell's slot is dense over the box padded to a multiple of 16 chunks per row:
+// not depend on any cell box; the skew by 3 per row spreads a wall seen edge-on over all tables.
+// Inside a table a cell's slot is dense over the frame's predicted cell box (rmin.., from the
+// host) padded to a multiple of 16 chunks per row:
 //   slot = ((row - rmin) * per_row + (cc - cc0) / 16) * 8 + col % 8,   per_row = ceil(ncc / 16).
 // A box whose padded cells exceed 16 tables of kSlots (about 131 thousand cells: far beyond what
-// a 5 m depth range reaches at 3 cm) is not binned; the winner kernel scans all cell ids then.
+// a 5 m depth range reaches at 3 cm) is not binned; the winner kernel scans the pixels then.
 constexpr int kBinParts = kMaxParts;          // 16 tables per frame
 constexpr int kBinShift = 4;
 constexpr int kChunkShift = 3, kChunkMask = (1 << kChunkShift) - 1;
@@ -362,13 +361,14 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     }
 }
 
-// One block = one table of kSlots consecutive cells of the frame's cell bounding box
-// (cells are numbered row-major inside the box).  Every block scans all cell ids of
-// its frame and keeps the pixels that fall into its table:
+// One block = one winner table of kSlots cells:
 //   phase a   table_h[slot] = max height image            (64-bit integer LDS max)
 //   phase b   table_i[slot] = min pixel index among the pixels that reach that max
 //   phase c   slots whose winner passes the filters are appended to the update list
-// Integer max / min are order independent, so the result is deterministic.
+// Integer max / min are order independent, so the result is deterministic.  On the binned path the
+// block reads the records the geometry kernel left for its table; on the scanning path (spilled
+// frames) table p holds cells p * kSlots .. of the frame's cell box numbered row-major, and the
+// block walks all pixels of the frame, recomputing their geometry.
 // A wave of the winner kernel takes every 16th geometry block, one lane per block for the
 // bookkeeping: frames of more than 1024 blocks (a million pixels) take the scanning path.
 constexpr int kMaxGeomBlocksBinned = (kWinnerThreads / 64) * 64;

@@ -182,17 +182,21 @@ struct BinFrame {
 };
 static_assert(kChunkShift == 3 && kRowSkew == 3, "geom_cell_table spells these constants out");
 __device__ inline int cell_table(uint32_t id) { return geom_cell_table(id); }
-__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
+__device__ inline BinFrame bin_frame_box(const int32_t *box) {   // box = {rmin, rmax, cmin, cmax}
     BinFrame f;
     f.on = false;
-    const int rmin = hdr->rmin, rmax = hdr->rmax, cmin = hdr->cmin, cmax = hdr->cmax;
-    if (rmin > rmax) return f;
+    const int rmin = box[0], rmax = box[1], cmin = box[2], cmax = box[3];
+    if (rmin > rmax || cmin > cmax) return f;
     f.rmin_b = rmin + kCoordBias;
     f.cc0 = (cmin + kCoordBias) >> kChunkShift;
     const int cc1 = (cmax + kCoordBias) >> kChunkShift;
     f.per_row = (cc1 - f.cc0 + kBinParts) >> kBinShift;
     f.on = ((long long)(rmax - rmin + 1) * f.per_row << kChunkShift) <= kSlots;
     return f;
+}
+__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
+    const int32_t box[4] = {hdr->rmin, hdr->rmax, hdr->cmin, hdr->cmax};
+    return bin_frame_box(box);
 }
 __device__ inline int cell_slot(const BinFrame &f, uint32_t id) {
     const int row_b = (int)((id >> kCoordBits) & kCoordMask), col_b = (int)(id & kCoordMask);
@@ -207,6 +211,18 @@ __device__ inline void slot_cell(const BinFrame &f, int table, int slot, int &ro
     const int j = ((table - f.cc0 - row_b * kRowSkew) & (kBinParts - 1)) + (kk << kBinShift);
     row = row_b - kCoordBias;
     col = (((f.cc0 + j) << kChunkShift) | (slot & kChunkMask)) - kCoordBias;
+}
+
+// Place `place` of geometry block b's share of table `part`.  Shares are stored in rows of 64
+// records, [place / 64][e][part][b][place % 64]: row 0 of all shares, which holds nearly all
+// records, is one dense range of memory, row 1 the next, instead of one short run every
+// kGeomPixPerBlock records.
+__device__ inline int64_t rec_table_base(const View &v, int e, int part) {
+    return ((int64_t)e * kBinParts + part) * v.geom_blocks * 64;
+}
+__device__ inline int64_t rec_offset(const View &v, int b, unsigned place) {
+    const int64_t row_stride = (int64_t)v.E * kBinParts * v.geom_blocks * 64;
+    return (int64_t)(place >> 6) * row_stride + (int64_t)(((unsigned)b << 6) | (place & 63u));
 }
 
 // One pass over the depth image.  The host predicts a cell box that contains every live pixel of
@@ -224,31 +240,6 @@ __device__ inline void slot_cell(const BinFrame &f, int table, int slot, int &ro
 // Block 0 of every env also writes the step's frame header and, when the poses travel as a kernel
 // argument (POSE_ARG, at most kPosePack envs), stores the env's pose for the later kernels.
 // PACKED: slot and pixel share one record word (frames of at most 2^kPackPixBits pixels).
-__device__ inline BinFrame bin_frame_box(const int32_t *box) {
-    BinFrame f;
-    f.on = false;
-    const int rmin = box[0], rmax = box[1], cmin = box[2], cmax = box[3];
-    if (rmin > rmax || cmin > cmax) return f;
-    f.rmin_b = rmin + kCoordBias;
-    f.cc0 = (cmin + kCoordBias) >> kChunkShift;
-    const int cc1 = (cmax + kCoordBias) >> kChunkShift;
-    f.per_row = (cc1 - f.cc0 + kBinParts) >> kBinShift;
-    f.on = ((long long)(rmax - rmin + 1) * f.per_row << kChunkShift) <= kSlots;
-    return f;
-}
-
-// Place `place` of geometry block b's share of table `part`.  Shares are stored in rows of 64
-// records, [place / 64][e][part][b][place % 64]: row 0 of all shares, which holds nearly all
-// records, is one dense range of memory, row 1 the next, instead of one short run every
-// kGeomPixPerBlock records.
-__device__ inline int64_t rec_table_base(const View &v, int e, int part) {
-    return ((int64_t)e * kBinParts + part) * v.geom_blocks * 64;
-}
-__device__ inline int64_t rec_offset(const View &v, int b, unsigned place) {
-    const int64_t row_stride = (int64_t)v.E * kBinParts * v.geom_blocks * 64;
-    return (int64_t)(place >> 6) * row_stride + (int64_t)(((unsigned)b << 6) | (place & 63u));
-}
-
 template <bool POSE_ARG, bool PACKED>
 __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all, PosePack pack, int write_target) {
     __shared__ unsigned int s_cnt[kBinParts];

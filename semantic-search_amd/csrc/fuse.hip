@@ -73,14 +73,17 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
 
-    // asked for first: one byte per pixel says whether it owns a map cell this step
-    uint8_t owns = 0;
-    if (MODE != 0 && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
         x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
-    // only the few owners fetch their list slot (needed last, after the softmax arithmetic)
+    // one byte per pixel says whether it owns a map cell this step; asked for after the class
+    // planes (the branch below waits for it at once, and a wave that waited for it before its C
+    // loads were in flight would lose a whole memory round trip).  Only the few owners then fetch
+    // their list slot.  (Reading the slot word of every pixel, to have no dependent load at all,
+    // measured the same: the extra 4 bytes per pixel cost what the shorter chain saves.)
+    uint8_t owns = 0;
+    if (MODE != 0 && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
     int slot = -1;
     if (MODE != 0 && owns) slot = v.target[fbase + pix];
 

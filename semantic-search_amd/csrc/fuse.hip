@@ -242,7 +242,14 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     const int64_t fbase = (int64_t)e * v.N;
     const unsigned n = v.hdr[e].n_winners;
     const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
-    const ssmap_env_maps &mp = v.envs[e].maps;
+    // the env's map pointers once, in registers: read through the struct they would be fetched
+    // again after every store (the stores could alias the struct), one more round trip in front
+    // of the row loads
+    const ssmap_env_maps &mp_ref = v.envs[e].maps;
+    float *const m_prob = mp_ref.prob_map, *const m_height = mp_ref.height_map;
+    float *const m_weight = mp_ref.weight_map, *const m_unc = mp_ref.unc_map;
+    uint32_t *const m_gt = mp_ref.gt_map, *const m_sem = mp_ref.semantic_map;
+    uint8_t *const m_color = mp_ref.semantic_map_color;
     const double agent_y = v.poses[e].agent[1];
     const int C = v.C;
     const float log_c = logf((float)C);
@@ -250,16 +257,18 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     const unsigned wave = threadIdx.x >> 6;
     for (unsigned r0 = blockIdx.x * kRun; r0 < n; r0 += gridDim.x * kRun) {
         // ---- side data of list slot r0 + lane (every wave: the new height feeds its stores)
+        // Loads are issued for every lane, from a safe address where the lane has nothing to do
+        // (slot 0, cell 0): a load inside a divergent branch is waited for at the end of that
+        // branch, which would turn the independent loads below into one round trip each.
         const unsigned is = r0 + lane;
-        const int2 ps = is < n ? list[is] : make_int2((int)kLostBit, 0);
-        const bool side_live = !((uint32_t)ps.x & kLostBit);
-        float hnew = 0.0f;
+        const int2 ps = list[is < n ? is : 0u];
+        const bool side_live = is < n && !((uint32_t)ps.x & kLostBit);
+        const int side_cell = side_live ? ps.y : 0;
+        const float h_old = m_height[side_cell];
+        const unsigned long long hk_side = v.wheight[fbase + (is < n ? is : 0u)];
         int gtv = 0;
-        if (side_live) {
-            const float h_old = mp.height_map[ps.y];
-            hnew = fmaxf(h_old, (float)(unorder_f64(v.wheight[fbase + is]) - agent_y));
-            if (gt && wave == 1) gtv = gt[fbase + (int)((uint32_t)ps.x & kPixMask)];
-        }
+        if (gt) gtv = gt[fbase + (side_live ? (int)((uint32_t)ps.x & kPixMask) : 0)];
+        const float hnew = fmaxf(h_old, (float)(unorder_f64(hk_side) - agent_y));
         // ---- rows
 #pragma unroll 1
         for (unsigned b0 = 0; b0 < 4; b0 += NB) {
@@ -273,29 +282,38 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                 const int j = 16 * wave + 4 * (b0 + b) + row;
                 const unsigned i = r0 + j;
                 const int2 pc = make_int2(__shfl(ps.x, j), __shfl(ps.y, j));
-                live[b] = !((uint32_t)pc.x & kLostBit);
-                cell[b] = pc.y;
-                w_old[b] = 0.0f;
+                live[b] = i < n && !((uint32_t)pc.x & kLostBit);
+                cell[b] = live[b] ? pc.y : 0;
+                // unconditional loads (cell 0 / slot 0 / class 0 where there is nothing to do), the
+                // unused values are zeroed afterwards
+                const float *mrow = m_prob + (int64_t)cell[b] * C;
+                const float *prow = v.wprob + (fbase + (live[b] ? i : 0u)) * v.wprob_stride;
 #pragma unroll
-                for (int k = 0; k < K; ++k) { mv[b][k] = 0.0f; p[b][k] = 0.0f; }
-                if (live[b]) {
-                    const float *mrow = mp.prob_map + (int64_t)cell[b] * C;
-                    const float *prow = v.wprob + (fbase + i) * v.wprob_stride;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int c = V * (sub + 16 * k);
-                        if (c < C) {
-                            mv[b][k] = *reinterpret_cast<const VecF *>(mrow + c);
-                            p[b][k] = *reinterpret_cast<const VecF *>(prow + c);
-                        }
-                    }
-                    if (MODE == 1) w_old[b] = mp.weight_map[cell[b]];
+                for (int k = 0; k < K; ++k) {
+                    const int c = V * (sub + 16 * k);
+                    const int cs = c < C ? c : 0;
+                    mv[b][k] = *reinterpret_cast<const VecF *>(mrow + cs);
+                    p[b][k] = *reinterpret_cast<const VecF *>(prow + cs);
                 }
+                w_old[b] = MODE == 1 ? m_weight[cell[b]] : 0.0f;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool used = live[b] && V * (sub + 16 * k) < C;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
+                        p[b][k][j] = used ? p[b][k][j] : 0.0f;
+                    }
+                }
+                if (!live[b]) w_old[b] = 0.0f;
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 // rows without a live cell still take part in the (row-local) DPP steps
-                float *mrow = mp.prob_map + (int64_t)cell[b] * C;
+                float *mrow = m_prob + (int64_t)cell[b] * C;
                 const bool on = live[b];
                 float best = -INFINITY;
                 int bi = 0x7FFFFFFF;
@@ -377,16 +395,16 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
             const int cell = ps.y;
             const int id = occupancy_override(v.lut[s_bi[lane]], hnew, v.use_height, v.n_schema);
             if (wave == 0) {
-                mp.height_map[cell] = hnew;
-                if (MODE == 1) mp.weight_map[cell] = s_wn[lane];
+                m_height[cell] = hnew;
+                if (MODE == 1) m_weight[cell] = s_wn[lane];
             } else if (wave == 1) {
-                if (gt) mp.gt_map[cell] = (uint32_t)gtv;
-                if (MODE == 1) mp.unc_map[cell] = s_ent[lane];
+                if (gt) m_gt[cell] = (uint32_t)gtv;
+                if (MODE == 1) m_unc[cell] = s_ent[lane];
             } else if (wave == 2) {
-                mp.semantic_map[cell] = (uint32_t)id;
+                m_sem[cell] = (uint32_t)id;
             } else {
                 const uint8_t *rgb = v.palette + 3 * id;
-                uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+                uint8_t *dst = m_color + 3ll * cell;
                 dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
             }
         }

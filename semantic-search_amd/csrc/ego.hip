@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0
     const int dy = i / t.out_w, dx = i - dy * t.out_w;
     const EgoAxis &ax = t.axis[which][0], &ay = t.axis[which][1];
     EgoView ev;
-    ev.mp = &v.envs[e].maps;
+    const ssmap_env_maps maps = v.envs[e].maps;   // by value: no pointer fetch in front of every gather
+    ev.mp = &maps;
     ev.pose = &s_pose;
     ev.tab = tables;
     ev.aux_points = s_aux;

@@ -104,7 +104,7 @@ __global__ void k_hv_revert(View v) {
     const int prev = v.cur_overlay ^ 1;
     const unsigned n = v.overlay_count[prev][e];
     const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
-    const ssmap_env_maps &mp = v.envs[e].maps;
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = list[i];
         mp.semantic_map[cell] = mp.background_map[cell];
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
     const int64_t fbase = (int64_t)e * v.N;
     const FrameHeader *hdr = v.hdr + e;
     const unsigned n = hdr->n_winners;
-    const ssmap_env_maps &mp = v.envs[e].maps;
-    const PoseBlock &pb = v.poses[e];
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const PoseBlock pb = v.poses[e];
     const int goal = pb.goal_id;
     const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
     const bool hv = v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV;
@@ -272,8 +272,8 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
     int r0, c0, bh, bw;
     if (!gd_box(hdr, r0, c0, bh, bw)) return;
     const unsigned n = hdr->n_winners;
-    const ssmap_env_maps &mp = v.envs[e].maps;
-    const PoseBlock &pb = v.poses[e];
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const PoseBlock pb = v.poses[e];
     const int goal = pb.goal_id;
     uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
     const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
@@ -349,7 +349,7 @@ __global__ void k_gd_apply(View v, int dil) {
     int r0, c0, bh, bw;
     if (!gd_box(hdr, r0, c0, bh, bw)) return;
     const bool any_goal = hdr->any_goal != 0;
-    const ssmap_env_maps &mp = v.envs[e].maps;
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     const int goal = v.poses[e].goal_id;
     const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
     const uint8_t *er = v.local_eroded + (int64_t)e * v.local_stride;
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
     __shared__ int s_cand[kFoundThreads];
     __shared__ unsigned int s_n;
     const int e = blockIdx.y;
-    const ssmap_env_maps &mp = v.envs[e].maps;
-    const PoseBlock &pb = v.poses[e];
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const PoseBlock pb = v.poses[e];
     const int goal = pb.goal_id;
     const int R = v.disk_radius, side = 2 * R + 1;
     const int C = v.C;
@@ -536,7 +536,7 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
 __global__ void k_path_paint(View v) {
     const int e = blockIdx.y;
     const unsigned n = v.path_count[e];
-    const ssmap_env_maps &mp = v.envs[e].maps;
+    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     const int32_t *cells = v.path_cells + (int64_t)e * v.path_cap;
     const int id = v.n_schema + 1;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -40,8 +40,9 @@ __device__ inline int occupancy_override(int id, float h, int use_height, int n_
 __device__ inline void commit_cell(const ssmap_env_maps &mp, const uint8_t *palette, int cell, int id) {
     mp.semantic_map[cell] = (uint32_t)id;
     const uint8_t *rgb = palette + 3 * id;
+    const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];   // all three before the first store (which could alias them)
     uint8_t *dst = mp.semantic_map_color + 3ll * cell;
-    dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+    dst[0] = r; dst[1] = g; dst[2] = b;
 }
 
 struct StreamArgs {
@@ -404,8 +405,9 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                 m_sem[cell] = (uint32_t)id;
             } else {
                 const uint8_t *rgb = v.palette + 3 * id;
+                const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];
                 uint8_t *dst = m_color + 3ll * cell;
-                dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+                dst[0] = r; dst[1] = g; dst[2] = b;
             }
         }
         __syncthreads();

@@ -25,8 +25,9 @@ __device__ inline int occupancy_override(int id, float h, int use_height, int n_
 
 __device__ inline void paint(const ssmap_env_maps &mp, const uint8_t *palette, int cell, int id) {
     const uint8_t *rgb = palette + 3 * id;
+    const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];   // all three before the first store (which could alias them)
     uint8_t *dst = mp.semantic_map_color + 3ll * cell;
-    dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+    dst[0] = r; dst[1] = g; dst[2] = b;
 }
 
 __device__ inline float raise_height(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
@@ -480,26 +481,43 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
             const unsigned k = k0 + row_id;
             const bool on = k < n_cand;
             const float *m = mp.prob_map + (int64_t)(on ? s_cand[k] : 0) * C;
+            // the cell's values of this lane (classes sub, sub + 16, ...) once, all loads in flight
+            // together; the probability rules take at most 155 classes
+            constexpr int kPer = 10;
+            float mv[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                const int c = sub + 16 * q;
+                mv[q] = m[c < C ? c : 0];
+            }
             float ent;
             if (avg) {
                 float s = 0.0f;
-                for (int c = sub; c < C; c += 16) s += on ? m[c] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) s += (on && sub + 16 * q < C) ? mv[q] : 0.0f;
                 s = row_sum(s);
                 float hs = 0.0f;
-                for (int c = sub; c < C; c += 16) hs += on ? entr_f(m[c] / s) : 0.0f;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) hs += (on && sub + 16 * q < C) ? entr_f(mv[q] / s) : 0.0f;
                 ent = row_sum(hs) / log_c;
             } else {   // softmax of the log-odds first (mapper.py:805-812)
                 float mx = -INFINITY;
-                for (int c = sub; c < C; c += 16) mx = fmaxf(mx, on ? m[c] : 0.0f);
+#pragma unroll
+                for (int q = 0; q < kPer; ++q)
+                    if (sub + 16 * q < C) mx = fmaxf(mx, on ? mv[q] : 0.0f);
                 mx = row_max(mx);
                 float s = 0.0f;
-                for (int c = sub; c < C; c += 16) s += on ? expf(m[c] - mx) : 0.0f;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) s += (on && sub + 16 * q < C) ? expf(mv[q] - mx) : 0.0f;
                 s = row_sum(s);
                 float s2 = 0.0f;
-                for (int c = sub; c < C; c += 16) s2 += on ? expf(m[c] - mx) / s : 0.0f;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) s2 += (on && sub + 16 * q < C) ? expf(mv[q] - mx) / s : 0.0f;
                 s2 = row_sum(s2);
                 float hs = 0.0f;
-                for (int c = sub; c < C; c += 16) hs += on ? entr_f((expf(m[c] - mx) / s) / s2) : 0.0f;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q)
+                    hs += (on && sub + 16 * q < C) ? entr_f((expf(mv[q] - mx) / s) / s2) : 0.0f;
                 ent = row_sum(hs) / log_c;
             }
             if (on && ent < v.prm.entropy_threshold) found = true;

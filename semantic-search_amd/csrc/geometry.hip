@@ -484,7 +484,8 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     if (!RUNS) {
         // scanned frame: the cells lie in the box of the spilled pixels, joined with the predicted
         // box when that one was in use (its pixels were not accumulated)
-        const bool pred = bin_frame(hdr).on;
+        const int32_t pb4[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
+        const bool pred = bin_frame_box(pb4).on;
         if (!pred) { rmin = cmin = 0x7FFFFFFF; rmax = cmax = (int)0x80000000; }
         rmin = min(rmin, acc->rmin); rmax = max(rmax, acc->rmax);
         cmin = min(cmin, acc->cmin); cmax = max(cmax, acc->cmax);
@@ -689,6 +690,8 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
         __syncthreads();
         unsigned n_neg = 0;
+        // the slot layout once for the whole emission (read here, where the record registers are free)
+        const BinFrame bf = bin_frame(hdr);
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int s = it * kWinnerThreads + threadIdx.x;
@@ -696,7 +699,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             const unsigned w = table_i[s];
             int row, col;
             if (RUNS) {
-                slot_cell(bin_frame(hdr), p, s, row, col);   // recomputed here: keeps it out of the registers above
+                slot_cell(bf, p, s, row, col);
             } else {
                 // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
                 const unsigned L = ((unsigned)p << kSlotShift) + (unsigned)s;

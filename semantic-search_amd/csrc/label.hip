@@ -99,7 +99,8 @@ __device__ inline bool goal_statistics(const View &v, const ssmap_env_maps &mp, 
 
 // hv rules rebuild semantic_map from background_map every frame (mapper.py:662, 723); the
 // engine keeps semantic_map == background_map except on the cells listed here, and undoes
-// last frame's list instead of copying the whole map.
+// last frame's list instead of copying the whole map.  The list has one entry per slot of that
+// frame's update list: the cell if it showed the goal overlay, -1 if not.
 __global__ void k_hv_revert(View v) {
     const int e = blockIdx.y;
     const int prev = v.cur_overlay ^ 1;
@@ -108,7 +109,7 @@ __global__ void k_hv_revert(View v) {
     const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = list[i];
-        mp.semantic_map[cell] = mp.background_map[cell];
+        if (cell >= 0) mp.semantic_map[cell] = mp.background_map[cell];
     }
 }
 
@@ -129,7 +130,11 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 pc = list[i];
         const uint32_t pw = (uint32_t)pc.x;
-        if (pw & kLostBit) continue;
+        if (hv && i == 0) v.overlay_count[v.cur_overlay][e] = n;
+        if (pw & kLostBit) {
+            if (hv) v.overlay[v.cur_overlay][fbase + i] = -1;
+            continue;
+        }
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
         // every gather of this cell is issued before the first store (the stores could alias the
@@ -230,19 +235,8 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
             const int shown = show ? goal : bg;
             mp.semantic_map[cell] = (uint32_t)shown;
             paint(mp, v.palette, cell, shown);
-            // one counter bump per wave: every shown cell bumping the env's counter itself would
-            // serialise thousands of same-address atomics
-            const unsigned long long shown_lanes = __ballot(show);
-            if (shown_lanes) {
-                const int cur = v.cur_overlay;
-                const int lane = threadIdx.x & 63;
-                const int leader = __ffsll((long long)shown_lanes) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(&v.overlay_count[cur][e], (unsigned)__popcll(shown_lanes));
-                base = __shfl(base, leader);
-                if (show)
-                    v.overlay[cur][(int64_t)e * v.N + base + (unsigned)__popcll(shown_lanes & ((1ull << lane) - 1ull))] = cell;
-            }
+            // slot i of the overlay list: no counter, so no same-address atomics
+            v.overlay[v.cur_overlay][fbase + i] = show ? cell : -1;
             continue;
         }
     }

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             h.status = 0;
             h.found = 0;
             h.any_goal = 0;
-            h.n_overlay = 0;
+            h.any_eroded = 0;
             h.n_neg = 0;
             h.pad = 0;
             v.hdr[e] = h;

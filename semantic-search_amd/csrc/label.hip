@@ -278,11 +278,17 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
         const bool lost = (pw & kLostBit) != 0;   // a later pixel writes the same wrapped cell
         const int pix = (int)(pw & kPixMask);
         const int cell = pc.y;
-        if (!lost) {
-            raise_height(v, mp, pb, fbase, i, cell);
-            mp.gt_map[cell] = (uint32_t)gt[fbase + pix];
-        }
+        // every gather before the first store (which could alias them as far as the compiler knows)
         int id = semantic[fbase + pix];
+        const int gtv = gt[fbase + pix];
+        const float h_old = mp.height_map[cell];
+        const unsigned long long hk = v.wheight[fbase + i];
+        if (!lost) {
+            mp.height_map[cell] = fmaxf(h_old, (float)(unorder_f64(hk) - pb.agent[1]));
+            mp.gt_map[cell] = (uint32_t)gtv;
+        }
+        // the uncertainty of the few goal pixels only: one more gather per pixel would cost more
+        // than the second round trip of these
         if (v.prm.use_filter && id == goal && (1.0f - unc[fbase + pix]) < v.prm.filter_goal_prob) id = 0;
         int row = cell / mp.map_w, col = cell - row * mp.map_w;
         if (pw & kRowNegBit) row -= mp.map_h;
@@ -296,7 +302,7 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
 // erosion of the goal mask by an n x n box anchored at n/2 with the outside counted as set
 __global__ void k_gd_erode(View v, int size) {
     const int e = blockIdx.y;
-    const FrameHeader *hdr = v.hdr + e;
+    FrameHeader *hdr = v.hdr + e;
     int r0, c0, bh, bw;
     if (!gd_box(hdr, r0, c0, bh, bw) || !hdr->any_goal) return;
     const uint8_t goal1 = (uint8_t)(v.poses[e].goal_id + 1);
@@ -317,6 +323,7 @@ __global__ void k_gd_erode(View v, int size) {
             }
         }
         er[i] = keep ? 1 : 0;
+        if (keep) hdr->any_eroded = 1u;
     }
 }
 
@@ -326,6 +333,7 @@ __device__ inline bool gd_member(const uint8_t *local, const uint8_t *er, int bh
     const int stored = local[(int64_t)r * bw + c] & (kGdLost - 1);
     id = stored ? stored - 1 : 0;
     if (id != goal && id != 0) return true;
+    if (!er) return false;   // nothing survived the erosion: the dilated mask is empty
     for (int dr = -lo; dr <= hi; ++dr) {
         const int rr = r + dr;
         if (rr < 0 || rr >= bh) continue;
@@ -347,7 +355,7 @@ __global__ void k_gd_apply(View v, int dil) {
     const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     const int goal = v.poses[e].goal_id;
     const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
-    const uint8_t *er = v.local_eroded + (int64_t)e * v.local_stride;
+    const uint8_t *er = hdr->any_eroded ? v.local_eroded + (int64_t)e * v.local_stride : nullptr;
     const int lo = (dil - 1) / 2, hi = (dil - 1) - lo;
     const int Hm = mp.map_h, Wm = mp.map_w;
     const bool may_wrap = r0 < 0 || c0 < 0;

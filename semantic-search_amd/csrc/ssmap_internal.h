@@ -58,7 +58,7 @@ struct FrameHeader {
     uint32_t status;
     int32_t found;
     uint32_t any_goal;                    // goal_decay: some update pixel carries the goal id
-    uint32_t n_overlay;                   // hv: goal overlays written this step
+    uint32_t any_eroded;                  // goal_decay: the eroded goal mask of this frame has a set cell
     uint32_t n_neg;                       // update cells reached through a negative (wrapped) index
     uint32_t pad;
 };

@@ -6,6 +6,8 @@ depth images (thousands of pixels in one cell), structured and uncorrelated dept
 Bar: update set, height map, ground-truth map and labels bit-exact; fused probabilities within
 rtol 1e-5 / atol 1e-6.  A scenario in which either side reports numpy's IndexError (a selected
 cell index below -dim) is only checked for that report."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,9 @@ from oracle import mapper_oracle as mo
 from tests import scenes
 
 pytestmark = pytest.mark.gpu
+
+# SSMAP_FUZZ_SCALE=8 runs eight times as many seeds of every generator (a wider one-off sweep)
+_SCALE = max(1, int(os.environ.get("SSMAP_FUZZ_SCALE", "1")))
 
 
 def _dev(a, dtype):
@@ -54,7 +59,7 @@ def _depth(sc, rng):
     return d
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(36 * _SCALE))
 def test_random_scenario_matches_oracle(seed):
     import semantic_search_amd as ssa
     sc = _scenario(seed)
@@ -111,7 +116,7 @@ def test_random_scenario_matches_oracle(seed):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
 def test_random_scenario_label_rules(seed):
     """The same scenario generator for the label rules that have exact wrap semantics (argmax with
     and without the goal filter, goal_decay, direct mapping): every integer map bit-exact."""
@@ -164,7 +169,7 @@ def test_random_scenario_label_rules(seed):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * _SCALE))
 def test_random_scenario_hit_view_rules(seed):
     """height_map_hv / height_map_prob_hv: background, hits, views and labels bit-exact, including
     update pixels that share a cell through the negative-index wrap (numpy applies every statement
@@ -217,7 +222,7 @@ def test_random_scenario_hit_view_rules(seed):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SCALE))
 def test_random_scenario_stubborn_rule(seed):
     """height_map_stubborn under the random scenarios: labels and view counts bit-exact, the
     float statistics within 1e-6 (sums of a few float32 probabilities in the same order)."""

@@ -21,6 +21,8 @@ import torch
 
 from . import engine as _engine
 
+_TORCH_DTYPES = {np.float32: torch.float32, np.int32: torch.int32}
+
 _MAP_NAMES = ("semantic_map", "semantic_map_color", "height_map", "gt_map", "unc_map", "goal_map",
               "log_odds_seg_map", "avg_prob_seg_map", "avg_prob_weight_map", "background_map",
               "hits", "views", "total_view", "cumulative_conf", "max_conf", "max_other_conf")
@@ -297,9 +299,14 @@ class SemanticMapper:
         goal_id = int(self.goal2sem_id[obs["objectgoal"]][0])
 
         def up(key, dtype):
+            # numpy arrays like the reference's callers pass, or torch tensors (a segmentation
+            # model's outputs that are already on the GPU skip the round trip through the host)
             if key not in obs or obs[key] is None:
                 return None
-            return torch.from_numpy(np.ascontiguousarray(obs[key], dtype=dtype)).to(dev).unsqueeze(0).contiguous()
+            val = obs[key]
+            if isinstance(val, torch.Tensor):
+                return val.detach().to(device=dev, dtype=_TORCH_DTYPES[dtype]).unsqueeze(0).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(val, dtype=dtype)).to(dev).unsqueeze(0).contiguous()
 
         d_depth = up("depth", np.float32)
         kwargs = {}
@@ -319,7 +326,11 @@ class SemanticMapper:
                  [goal_id], **kwargs)
         found, status, n_upd = eng.results()
         # the reference zeroes the sentinels in the caller's array (mapper.py:282-283)
-        depth[...] = d_depth[0].cpu().numpy()
+        if isinstance(depth, torch.Tensor):
+            if depth.data_ptr() != d_depth.data_ptr():
+                depth.copy_(d_depth[0])
+        else:
+            depth[...] = d_depth[0].cpu().numpy()
         self._host_cache = {}
         self.last_status, self.last_n_updates = int(status[0]), int(n_upd[0])
         if status[0] & 1:

@@ -494,3 +494,40 @@ def test_frame_without_any_valid_depth_updates_nothing():
     assert found is None and m.last_n_updates == 0
     assert not obs["depth"].any() and not m.semantic_map.any()
     assert np.isneginf(m.height_map).all()
+
+
+def test_update_map_takes_torch_tensors_like_numpy_arrays():
+    """Observations that are torch tensors (host or GPU) give the maps the numpy arrays give; the
+    sentinels of a GPU depth tensor are zeroed in place like those of a numpy depth image."""
+    import torch
+    import semantic_search_amd as ssa
+    lut = scenes.small_lut(8)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_log_odds", seg_model_n_classes=8)
+    bounds = np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5])
+    mappers = []
+    for _ in range(2):
+        m = ssa.SemanticMapper(**kw)
+        m.map_seg_to_schema = lambda ids: lut[ids]
+        m.reset(bounds)
+        mappers.append(m)
+    rng = np.random.default_rng(5)
+    for i in range(3):
+        agent, cam = scenes.make_pose(1.5 + 0.2 * i, 0.0, 1.2, 0.8 - 0.3 * i)
+        frame = scenes.room_frame(rng, 96, 128, 8, 1.0, cam, lut=lut)
+        frame["depth"][0, :5] = 0.5                      # sentinels (mapper.py:282-283)
+        obs_np = scenes.make_obs(frame, agent, cam, goal_index=0)
+        obs_t = dict(obs_np)
+        for k in ("depth", "semantic_prob", "semantic_gt"):
+            obs_t[k] = torch.from_numpy(obs_np[k].copy())
+            if k != "semantic_gt":
+                obs_t[k] = obs_t[k].cuda()                # one observation stays on the host
+        ego_a, found_a = mappers[0].update_map(obs_np)
+        ego_b, found_b = mappers[1].update_map(obs_t)
+        assert found_a == found_b
+        assert np.array_equal(obs_np["depth"], obs_t["depth"].cpu().numpy())
+        assert (obs_np["depth"][0, :5] == 0).all()
+        for a, b in zip(ego_a, ego_b):
+            assert np.array_equal(a, b)
+    for name in ("semantic_map", "height_map", "gt_map", "log_odds_seg_map", "unc_map", "semantic_map_color"):
+        assert np.array_equal(getattr(mappers[0], name), getattr(mappers[1], name), equal_nan=True), name

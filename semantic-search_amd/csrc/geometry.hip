@@ -311,14 +311,26 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
         }
         if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
         if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+        // at most kGeomPixPerBlock live pixels in a block: the place is inside the block's share.
+        // The four places are asked for together, so that one wait covers the four LDS round trips.
+        unsigned place4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            place4[k] = part_slot[k] != kDeadCell ? atomicAdd(&s_cnt[part_slot[k] >> 16], 1u) : 0u;
+        // rec_table_base + rec_offset with the block's part in scalar registers and 32-bit lane
+        // arithmetic: a row of places (E * 16 * geom_blocks * 64 of them) is far below 2^32, the
+        // sixteen rows of 12-byte records would not fit the GPU's memory otherwise
+        const int64_t blk_base = rec_table_base(v, e, 0) + ((int64_t)blockIdx.x << 6);
+        const uint32_t part_stride = (uint32_t)v.geom_blocks * 64u;
+        const uint32_t row_stride = (uint32_t)v.E * kBinParts * part_stride;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (part_slot[k] == kDeadCell) continue;
             const int part = (int)(part_slot[k] >> 16);
             const unsigned slot = part_slot[k] & 0xFFFFu;
-            // at most kGeomPixPerBlock live pixels in a block: the place is inside the block's share
-            const unsigned place = atomicAdd(&s_cnt[part], 1u);
-            const int64_t at = rec_table_base(v, e, part) + rec_offset(v, blockIdx.x, place);
+            const unsigned place = place4[k];
+            const int64_t at = blk_base + (int64_t)((uint64_t)(place >> 6) * row_stride +
+                                                    ((uint32_t)part * part_stride + (place & 63u)));
             v.rec_h[at] = hk[k];
             if (PACKED) {
                 v.rec_w[at] = (slot << kPackPixBits) | (unsigned)(i0 + k);

@@ -67,7 +67,7 @@ typedef enum ssmap_rule {
  * plus the frame geometry. */
 typedef struct ssmap_config {
     int32_t n_envs;              /* E: environments stepped per call */
-    int32_t img_h, img_w;        /* H, W of every frame */
+    int32_t img_h, img_w;        /* H, W of every frame (any size; widths that are a multiple of 4 read the depth 16 bytes at a time) */
     int32_t n_classes;           /* C = seg_model_n_classes; 0 when no class tensor is used */
     int32_t n_schema;            /* num_semantic_classes (9 for the ObjectNav schema) */
     int32_t rule;                /* ssmap_rule */

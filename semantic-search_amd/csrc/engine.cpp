@@ -182,8 +182,8 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     if (!cfg || !out) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     const ssmap_config &c = *cfg;
-    if (c.n_envs < 1 || c.img_h < 1 || c.img_w < 4 || (c.img_w % 4) != 0)
-        return fail(SSMAP_ERR_INVALID_ARG, "n_envs >= 1, img_h >= 1 and img_w a positive multiple of 4 are required");
+    if (c.n_envs < 1 || c.img_h < 1 || c.img_w < 1)
+        return fail(SSMAP_ERR_INVALID_ARG, "n_envs >= 1, img_h >= 1 and img_w >= 1 are required");
     if ((int64_t)c.img_h * c.img_w >= (1 << 29))
         return fail(SSMAP_ERR_INVALID_ARG, "frame too large");
     if (c.rule < SSMAP_RULE_DIRECT || c.rule > SSMAP_RULE_STUBBORN)

@@ -240,7 +240,9 @@ __device__ inline int64_t rec_offset(const View &v, int b, unsigned place) {
 // Block 0 of every env also writes the step's frame header and, when the poses travel as a kernel
 // argument (POSE_ARG, at most kPosePack envs), stores the env's pose for the later kernels.
 // PACKED: slot and pixel share one record word (frames of at most 2^kPackPixBits pixels).
-template <bool POSE_ARG, bool PACKED>
+// QUAD: the image width is a multiple of four, so a thread's four pixels lie in one image row and
+// their depths are one aligned 16-byte load; other widths take the four pixels one by one.
+template <bool POSE_ARG, bool PACKED, bool QUAD>
 __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ depth_all, PosePack pack, int write_target) {
     __shared__ unsigned int s_cnt[kBinParts];
     __shared__ unsigned int s_inv, s_err, s_spill;
@@ -286,16 +288,34 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     if (i0 < v.N) {
         const int r = i0 / v.W;
         const int c0 = i0 - r * v.W;
-        const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
-        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        float d[4];
+        if (QUAD) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(depth_all + fbase + i0);
+            d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = i0 + k < v.N ? depth_all[fbase + i0 + k] : 0.0f;
+        }
         const double yr = (double)r - (double)v.H / 2.0;
         bool dirty = false;
         uint32_t part_slot[4];          // table << 16 | slot, or kDeadCell
         unsigned long long hk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (d[k] == v.depth_min || d[k] == v.depth_max) { d[k] = 0.0f; dirty = true; }   // mapper.py:279-283
-            const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
+            if (!QUAD && i0 + k >= v.N) { hk[k] = 0; part_slot[k] = kDeadCell; continue; }   // past the frame's end
+            if (d[k] == v.depth_min || d[k] == v.depth_max) {   // mapper.py:279-283
+                d[k] = 0.0f;
+                dirty = true;
+                if (!QUAD) depth_all[fbase + i0 + k] = 0.0f;
+            }
+            int ck = c0 + k;
+            double yrk = yr;
+            if (!QUAD) {
+                const int rk = (i0 + k) / v.W;
+                ck = i0 + k - rk * v.W;
+                yrk = (double)rk - (double)v.H / 2.0;
+            }
+            const PixelGeom g = pixel_geometry(v, pb, mp, d[k], ck, yrk);
             hk[k] = g.key;
             part_slot[k] = kDeadCell;
             if (g.index_error) err |= SSMAP_ENV_INDEX_ERROR;
@@ -309,8 +329,16 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
                 scmin = min(scmin, g.col); scmax = max(scmax, g.col);
             }
         }
-        if (dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
-        if (write_target) *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+        if (QUAD && dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
+        if (write_target) {
+            if (QUAD) {
+                *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k < v.N) v.wflag[fbase + i0 + k] = 0;
+            }
+        }
         // at most kGeomPixPerBlock live pixels in a block: the place is inside the block's share.
         // The four places are asked for together, so that one wait covers the four LDS round trips.
         unsigned place4[4];
@@ -540,8 +568,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             inv_slot = (int)(inv_L & (kSlots - 1));
         }
     }
-    const float4 *depth4 = reinterpret_cast<const float4 *>(depth_all + fbase);   // sentinels already zeroed
-    const int n4 = v.N >> 2;
+    const float *depth_env = depth_all + fbase;   // sentinels already zeroed
     constexpr int kWaves = kWinnerThreads / 64;
     constexpr int kKeep = RUNS ? (PACKED ? 19 : 14) : 1;   // records per thread kept in registers between the phases
     Rec<PACKED> keep[kKeep], tail0;
@@ -622,17 +649,12 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         } else {
         // scanned frame: the geometry is computed again for every table pass (rare, and exact
         // by construction: the same function, the same inputs)
-        for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
-            const float4 d4 = depth4[q];
-            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
-            const int r = (4 * q) / v.W, c0 = 4 * q - r * v.W;
-            const double yr = (double)r - (double)v.H / 2.0;
-            for (int k = 0; k < 4; ++k) {
-                const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
-                if (g.id == kDeadCell) continue;
-                const int L = (g.row - rmin) * bw + (g.col - cmin);
-                if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], g.key);
-            }
+        for (int i = threadIdx.x; i < v.N; i += kWinnerThreads) {
+            const int r = i / v.W, c = i - r * v.W;
+            const PixelGeom g = pixel_geometry(v, pb, mp, depth_env[i], c, (double)r - (double)v.H / 2.0);
+            if (g.id == kDeadCell) continue;
+            const int L = (g.row - rmin) * bw + (g.col - cmin);
+            if ((L >> kSlotShift) == p) atomicMax(&table_h[L & (kSlots - 1)], g.key);
         }
         }
         __syncthreads();
@@ -655,20 +677,14 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
                 if (table_h[rec.slot()] == rec.h) atomicMin(&table_i[rec.slot()], rec.word());
             }
         } else {
-        for (int q = threadIdx.x; q < n4; q += kWinnerThreads) {
-            const float4 d4 = depth4[q];
-            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
-            const int r = (4 * q) / v.W, c0 = 4 * q - r * v.W;
-            const double yr = (double)r - (double)v.H / 2.0;
-            for (int k = 0; k < 4; ++k) {
-                const PixelGeom g = pixel_geometry(v, pb, mp, d[k], c0 + k, yr);
-                if (g.id == kDeadCell) continue;
-                const int L = (g.row - rmin) * bw + (g.col - cmin);
-                if ((L >> kSlotShift) == p) {
-                    const int s = L & (kSlots - 1);
-                    if (g.key == table_h[s])
-                        atomicMin(&table_i[s], (unsigned)(4 * q + k) << 1);
-                }
+        for (int i = threadIdx.x; i < v.N; i += kWinnerThreads) {
+            const int r = i / v.W, c = i - r * v.W;
+            const PixelGeom g = pixel_geometry(v, pb, mp, depth_env[i], c, (double)r - (double)v.H / 2.0);
+            if (g.id == kDeadCell) continue;
+            const int L = (g.row - rmin) * bw + (g.col - cmin);
+            if ((L >> kSlotShift) == p) {
+                const int s = L & (kSlots - 1);
+                if (g.key == table_h[s]) atomicMin(&table_i[s], (unsigned)i << 1);
             }
         }
         }
@@ -845,14 +861,21 @@ void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host
     const int wt = prob_rule ? 1 : 0;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
     PosePack pack;
-    if (host_poses) {   // at most kPosePack envs
-        memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);
-        if (v.rec_packed) hipLaunchKernelGGL((k_geometry<true, true>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
-        else hipLaunchKernelGGL((k_geometry<true, false>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
-    } else {
-        if (v.rec_packed) hipLaunchKernelGGL((k_geometry<false, true>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
-        else hipLaunchKernelGGL((k_geometry<false, false>), grid, dim3(256), 0, s, v, f.depth, pack, wt);
+    if (host_poses) memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);   // at most kPosePack envs
+    const int variant = (host_poses ? 4 : 0) | (v.rec_packed ? 2 : 0) | ((v.W & 3) == 0 ? 1 : 0);
+#define SSMAP_GEOMETRY(POSE, PACKED, QUAD) \
+    hipLaunchKernelGGL((k_geometry<POSE, PACKED, QUAD>), grid, dim3(256), 0, s, v, f.depth, pack, wt)
+    switch (variant) {
+        case 7: SSMAP_GEOMETRY(true, true, true); break;
+        case 6: SSMAP_GEOMETRY(true, true, false); break;
+        case 5: SSMAP_GEOMETRY(true, false, true); break;
+        case 4: SSMAP_GEOMETRY(true, false, false); break;
+        case 3: SSMAP_GEOMETRY(false, true, true); break;
+        case 2: SSMAP_GEOMETRY(false, true, false); break;
+        case 1: SSMAP_GEOMETRY(false, false, true); break;
+        default: SSMAP_GEOMETRY(false, false, false); break;
     }
+#undef SSMAP_GEOMETRY
 }
 
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {

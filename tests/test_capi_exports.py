@@ -55,7 +55,7 @@ def test_create_rejects_configs_before_touching_the_gpu():
         kw.update(over)
         return c.Config(**kw)
 
-    for bad, text in ((dict(img_w=62), "multiple of 4"), (dict(fx=1e12), "fx, fy"), (dict(pixel2meter=0.0), "positive"),
+    for bad, text in ((dict(img_w=0), "img_w >= 1"), (dict(fx=1e12), "fx, fy"), (dict(pixel2meter=0.0), "positive"),
                       (dict(rule=99), "prob_aggregate"), (dict(max_map_w=9000), "map dimensions")):
         handle = ctypes.c_void_p()
         rc = lib.ssmap_create(ctypes.byref(cfg(**bad)), ctypes.byref(handle))

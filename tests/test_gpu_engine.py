@@ -364,12 +364,13 @@ def test_full_size_label_rules_from_logits(rule, attrs, filt):
     eng.close()
 
 
-@pytest.mark.parametrize("n_envs", [3, 18])
-def test_batched_engine_equals_independent_engines(n_envs):
+@pytest.mark.parametrize("n_envs,hw", [(3, (96, 128)), (18, (96, 128)), (3, (45, 67))])
+def test_batched_engine_equals_independent_engines(n_envs, hw):
     """E envs with different map sizes and poses in one call == E engines of one env each.
-    (Up to 16 envs the poses travel as kernel arguments, above through a staging copy.)"""
+    (Up to 16 envs the poses travel as kernel arguments, above through a staging copy.  With the
+    45x67 frames an env's pixels do not start at a multiple of four in the batch.)"""
     import semantic_search_amd as ssa
-    h, w, c = 96, 128, 8
+    (h, w), c = hw, 8
     lut = scenes.small_lut(c)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
@@ -397,14 +398,18 @@ def test_batched_engine_equals_independent_engines(n_envs):
         depth = np.stack([f["depth"] for f in frames])
         probs = np.stack([f["semantic_prob"] for f in frames])
         gt = np.stack([f["semantic_gt"] for f in frames])
-        big.step(_to_dev(depth, np.float32), np.stack(ag), np.stack(cam), goals,
+        depth[:, 0, :3] = 0.5                                  # sentinels, zeroed in place by the step
+        d_big = _to_dev(depth, np.float32)
+        big.step(d_big, np.stack(ag), np.stack(cam), goals,
                  probs=_to_dev(probs, np.float32), semantic_gt=_to_dev(gt, np.int32))
         fb, sb, nb = big.results()
         for e in range(n_envs):
-            singles[e].step(_to_dev(depth[e:e + 1], np.float32), ag[e][None], cam[e][None], [goals[e]],
+            d_one = _to_dev(depth[e:e + 1], np.float32)
+            singles[e].step(d_one, ag[e][None], cam[e][None], [goals[e]],
                             probs=_to_dev(probs[e:e + 1], np.float32), semantic_gt=_to_dev(gt[e:e + 1], np.int32))
             f1, s1_, n1 = singles[e].results()
             assert (fb[e], sb[e], nb[e]) == (f1[0], s1_[0], n1[0])
+            assert torch.equal(d_big[e], d_one[0]) and (d_one[0, 0, :3] == 0).all()
     for e in range(n_envs):
         for nm, t in big.maps[e].items():
             assert torch.equal(t, singles[e].maps[0][nm]), (e, nm)

@@ -89,16 +89,18 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     if (MODE != 0 && owns) slot = v.target[fbase + pix];
 
     if (a.from_logits) {
-        // no implicit fused multiply-add in here: x k - max(x k) must be exactly 0 at the max
+        // no implicit fused multiply-add in here: the roundings are those of the reference's
+        // y = x / T, y - max(y)
 #pragma clang fp contract(off)
-        // softmax(x / T) in base 2: exp(y - max y) = exp2(x k - max(x k)), k = log2(e) / T
-        const float k2 = a.inv_t * 1.44269504088896341f;
+        // softmax(y), y = x * (1 / T) rounded to float32 like the reference's scaled logits, so that
+        // logits of any magnitude give the reference's differences y - max(y); the exponential in
+        // base 2: exp(d) = exp2(d log2(e)), exactly 1 at the max
         float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { x[c] *= k2; m = fmaxf(m, x[c]); }
+        for (int c = 0; c < CT; ++c) { x[c] *= a.inv_t; m = fmaxf(m, x[c]); }
         float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { x[c] = __builtin_amdgcn_exp2f(x[c] - m); s += x[c]; }
+        for (int c = 0; c < CT; ++c) { x[c] = __builtin_amdgcn_exp2f((x[c] - m) * 1.44269504088896341f); s += x[c]; }
         const float inv_s = 1.0f / s;
         // the class at the max has exp2(0) = 1, so the largest probability is inv_s itself;
         // ties go to the lowest class index like argmax does

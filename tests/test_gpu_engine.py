@@ -67,6 +67,51 @@ def test_stage1_matches_oracle(n_classes, temperature):
     eng.close()
 
 
+@pytest.mark.parametrize("n_classes", [40, 13])
+def test_stage1_edge_logits(n_classes):
+    """Exact ties (argmax takes the lowest class), one class dominating until the softmax saturates,
+    classes masked with -inf, and logits of large magnitude: labels bit-exact, floats within rtol
+    1e-5.  13 classes take the generic kernel, 40 the register kernel."""
+    import semantic_search_amd as ssa
+    h, w = 24, 32
+    rng = np.random.default_rng(7)
+    logits = (2.0 * rng.standard_normal((1, n_classes, h, w))).astype(np.float32)
+    logits[0, :, 0, :] = 1.25                                  # every class equal
+    logits[0, :, 1, :] = 0.0
+    logits[0, 3, 1, :] = 0.5
+    logits[0, 7, 1, :] = 0.5                                   # two leaders tie exactly: class 3 wins
+    logits[0, :, 2, :] = -3.0
+    logits[0, 5, 2, :] = 400.0                                 # saturated: p = 1, entropy = 0
+    logits[0, 1::2, 3, :] = -np.inf                            # masked classes
+    logits[0, :, 4, :] *= 1.0e4                                # large magnitudes, both signs (compared at T = 1)
+    logits[0, :, 6, :] *= 30.0
+    logits[0, :, 5, :] = -1.0e30
+    logits[0, 2, 5, :] = -1.0e30 + 1.0e24
+    lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
+    eng = ssa.MapEngine(1, (h, w), depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+                        prob_aggregate="height_map_argmax", seg_model_n_classes=n_classes, max_map_hw=(100, 100))
+    eng.set_schema(lut)
+    for temperature in (1.0, 3.2):
+        if temperature != 1.0:
+            # x / T (the oracle, torch on the CPU) and x * (1 / T) (torch on a GPU, and the engine)
+            # differ by an ulp of the scaled logit now and then, which at 1e4 is 1e-3: that row is
+            # only comparable where the division is exact
+            logits[0, :, 4, :] = logits[0, :, 6, :]
+        out = eng.stage1(_to_dev(logits, np.float32), temperature, want_probs=True)
+        torch.cuda.synchronize()
+        want = s1.predict_tail(logits[0], temperature, lut)
+        probs = out["semantic_prob"][0].cpu().numpy()
+        assert np.isfinite(probs).all() and np.isfinite(want["semantic_prob"]).all()
+        _close(probs, want["semantic_prob"], "semantic_prob", atol=1e-9)
+        _close(out["semantic_unc"][0].cpu().numpy(), want["semantic_unc"], "semantic_unc", atol=2e-6)
+        sem = out["semantic"][0].cpu().numpy()
+        rows = slice(0, 7)                                      # the constructed rows have no near-ties
+        assert np.array_equal(sem[rows], want["semantic"][rows])
+        assert (sem[1] == lut[3]).all() and (sem[2] == lut[5]).all()
+        _close(out["semantic_max_prob"][0].cpu().numpy()[rows], want["semantic_max_prob"][rows], "semantic_max_prob")
+    eng.close()
+
+
 def _run_pair(rule, n_classes, temperature, n_frames, hw, from_logits, attrs=None, filter_goal_prob=None,
               seed=0, bounds=BOUNDS_480, center=7.2):
     """Drives the engine (E=1, device-resident inputs) and the oracle over the same frames."""

@@ -60,8 +60,22 @@ def _depth(sc, rng):
     return d
 
 
+def _degenerate(probs, rng):
+    """One-hot rows (exact zeros and ones), all-zero rows and denormal-small rows among the
+    probability vectors: the log-odds of these are infinities, the averages divide by zero."""
+    c, h, w = probs.shape
+    kind = rng.random((h, w))
+    hot = rng.integers(0, c, (h, w))
+    onehot = (np.arange(c)[:, None, None] == hot[None]).astype(np.float32)
+    probs = np.where(kind[None] < 0.2, onehot, probs)
+    probs = np.where((kind[None] >= 0.2) & (kind[None] < 0.25), np.float32(0.0), probs)
+    probs = np.where((kind[None] >= 0.25) & (kind[None] < 0.3), np.float32(1e-40) * onehot, probs)
+    return np.ascontiguousarray(probs, dtype=np.float32)
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
 @pytest.mark.parametrize("seed", range(36 * _SCALE))
-def test_random_scenario_matches_oracle(seed):
+def test_random_scenario_matches_oracle(seed, degenerate):
     import semantic_search_amd as ssa
     sc = _scenario(seed)
     rng, (h, w), c = sc["rng"], sc["hw"], sc["c"]
@@ -77,13 +91,16 @@ def test_random_scenario_matches_oracle(seed):
     for i in range(3):
         frame = scenes.uniform_frame(rng, h, w, c, 1.0, lut=lut)
         frame["depth"] = _depth(sc, rng)
+        if degenerate:
+            frame["semantic_prob"] = _degenerate(frame["semantic_prob"], rng)
         agent, cam = scenes.make_pose(sc["agent"][0] + 0.2 * i, sc["floor"], sc["agent"][1], rng.uniform(0, 2 * np.pi),
                                       pitch=sc["pitch"])
         obs = scenes.make_obs(frame, agent, cam, goal_index=0)
         obs["depth"] = frame["depth"].copy()
         raised = False
         try:
-            ref.update(obs)
+            with np.errstate(all="ignore"):
+                ref.update(obs)
         except IndexError:
             raised = True
         eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],

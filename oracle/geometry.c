@@ -53,6 +53,8 @@ void oracle_project(float *depth, int32_t H, int32_t W,
             const double wx = fma(rot[2], z, fma(rot[1], y, rot[0] * x)) + trans[0];
             const double wy = fma(rot[5], z, fma(rot[4], y, rot[3] * x)) + trans[1];
             const double wz = fma(rot[8], z, fma(rot[7], y, rot[6] * x)) + trans[2];
+            /* numpy's astype(int) on x86-64 (cvttsd2si): NaN, infinities and values beyond the
+             * int64 range become INT64_MIN; this cast compiles to the same instruction */
             row[i] = (int64_t)floor((wz - lower[2]) / pixel2meter);
             col[i] = (int64_t)floor((wx - lower[0]) / pixel2meter);
             height[i] = wy;

@@ -127,9 +127,13 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
     g.key = 0;
     g.row = g.col = 0;
     g.invalid = !ok;
-    // comparisons in double so that huge or non-finite coordinates never reach a cast
-    const bool below_upper = fr < (double)Hm && fc < (double)Wm;
-    const bool above_lower = fr >= -(double)Hm && fc >= -(double)Wm;
+    // Comparisons in double so that huge or non-finite coordinates never reach a cast.  numpy
+    // casts the floored coordinate to int64 (mapper.py:863), and the x86 conversion turns a NaN,
+    // an infinity and any value beyond the int64 range into INT64_MIN: such a coordinate passes
+    // the upper-bound mask and is an index far below -dim.
+    const bool r_min = !(fr < 9223372036854775808.0), c_min = !(fc < 9223372036854775808.0);
+    const bool below_upper = (r_min || fr < (double)Hm) && (c_min || fc < (double)Wm);
+    const bool above_lower = !r_min && !c_min && fr >= -(double)Hm && fc >= -(double)Wm;
     const bool pass = ok && (wy < pb.h_cut);
     g.in_box = below_upper && above_lower && wy == wy;
     g.index_error = !g.in_box && below_upper && !above_lower && pass;   // index below -dim: numpy raises IndexError

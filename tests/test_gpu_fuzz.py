@@ -37,7 +37,7 @@ def _scenario(seed):
     ax = rng.uniform(lower[0] - 1.0, lower[0] + span_x + 1.0)
     az = rng.uniform(lower[2] - 1.0, lower[2] + span_z + 1.0)
     pitch = rng.choice([scenes.CAM_PITCH, 0.0, -0.8, 0.3])
-    kind = ["uniform", "flat", "beyond", "near"][int(rng.integers(0, 4))]
+    kind = ["uniform", "flat", "beyond", "near", "broken", "infinite"][int(rng.integers(0, 6))]
     rule = ["height_map_avg_prob", "height_map_log_odds", "avg_prob"][int(rng.integers(0, 3))]
     return dict(rng=rng, hw=(h, w), c=c, bounds=bounds, agent=(ax, az), pitch=float(pitch), kind=kind,
                 rule=rule, floor=float(lower[1]))
@@ -54,6 +54,15 @@ def _depth(sc, rng):
         d[far] = rng.uniform(5.5, 12.0, int(far.sum())).astype(np.float32)
     elif sc["kind"] == "near":        # everything within a metre: a handful of cells
         d = rng.uniform(0.5, 1.0, (h, w)).astype(np.float32)
+    elif sc["kind"] in ("broken", "infinite"):   # a sensor that reports NaN, zeros, negative depths ...
+        bad = rng.random((h, w))
+        d[bad < 0.02] = np.float32(np.nan)
+        d[(bad >= 0.04) & (bad < 0.06)] = np.float32(-np.inf)
+        d[(bad >= 0.06) & (bad < 0.08)] = np.float32(-1.5)
+        d[(bad >= 0.08) & (bad < 0.10)] = np.float32(0.0)
+        if sc["kind"] == "infinite":             # ... and +inf: cell indices that numpy casts to INT64_MIN
+            d[(bad >= 0.02) & (bad < 0.04)] = np.float32(np.inf)
+            d[(bad >= 0.10) & (bad < 0.11)] = np.float32(3.0e38)
     sentinel = rng.random((h, w))
     d[sentinel < 0.01] = np.float32(0.5)
     d[sentinel > 0.99] = np.float32(5.0)

@@ -443,6 +443,9 @@ def test_batched_engine_equals_independent_engines(n_envs, hw):
         depth = np.stack([f["depth"] for f in frames])
         probs = np.stack([f["semantic_prob"] for f in frames])
         gt = np.stack([f["semantic_gt"] for f in frames])
+        for e in range(1, n_envs, 3):                          # every third env leaves its predicted cell box
+            far = rng.random((h, w)) < 0.03                    # (depths beyond depth_max): scanned, the others binned
+            depth[e][far] = rng.uniform(5.5, 11.0, int(far.sum())).astype(np.float32)
         depth[:, 0, :3] = 0.5                                  # sentinels, zeroed in place by the step
         d_big = _to_dev(depth, np.float32)
         big.step(d_big, np.stack(ag), np.stack(cam), goals,

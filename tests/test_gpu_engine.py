@@ -67,7 +67,7 @@ def test_stage1_matches_oracle(n_classes, temperature):
     eng.close()
 
 
-@pytest.mark.parametrize("n_classes", [40, 13])
+@pytest.mark.parametrize("n_classes", [40, 13, 150])
 def test_stage1_edge_logits(n_classes):
     """Exact ties (argmax takes the lowest class), one class dominating until the softmax saturates,
     classes masked with -inf, and logits of large magnitude: labels bit-exact, floats within rtol

@@ -159,14 +159,16 @@ def resize_area_shrink_u8(src, dsize_wh):
 
 
 def resize_area_integer_u8(src, dsize_wh):
-    """INTER_AREA with integer factors: plain box mean, (sum * (1/area)) in float32, rounded.
-    (Not the factor 2 x 2, which OpenCV rounds as (sum + 2) >> 2; the ego maps never hit it.)"""
+    """INTER_AREA with integer factors: plain box mean, (sum * (1/area)) in float32, rounded;
+    the factor 2 x 2 is rounded half up in integers, (sum + 2) >> 2; factor 1 is a copy."""
     sh, sw = src.shape[:2]
     dw, dh = dsize_wh
     fx, fy = sw // dw, sh // dh
     cn = src.shape[2] if src.ndim == 3 else 1
     S = src.reshape(sh, sw, cn).astype(np.int64)
     sums = S.reshape(dh, fy, dw, fx, cn).sum(axis=(1, 3))
+    if fx == 2 and fy == 2:
+        return ((sums + 2) >> 2).astype(np.uint8).reshape((dh, dw) + src.shape[2:])
     out = np.clip(np.rint(sums.astype(np.float32) * np.float32(1.0 / (fx * fy))), 0, 255).astype(np.uint8)
     return out.reshape((dh, dw) + src.shape[2:])
 

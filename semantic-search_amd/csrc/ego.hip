@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0
     const int off = t.crop_off[which];             // centre crop of the rotated image (mapper.py:937-946)
     uint8_t *dst = (which ? ego_large : ego_small) + ((int64_t)e * t.out_h * t.out_w + i) * 3;
 
-    if (t.mode[which] == kEgoArea) {
+    if (t.mode[which] != kEgoLinear) {
         // column taps of this output pixel: source column, weight, fixed-point column terms
         const int nx = ax.count[dx], ny = ay.count[dy];
         int sxk[kEgoMaxTaps], adk[kEgoMaxTaps], bdk[kEgoMaxTaps];
@@ -172,8 +172,17 @@ __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0
 #pragma unroll
             for (int c = 0; c < 3; ++c) sum[c] = sum[c] + beta * buf[c];
         }
+        if (t.mode[which] == kEgoBox) {
+            // integer factors: the taps have weight one, so `sum` is the block's exact integer sum.
+            // 2 x 2 blocks are rounded half up in integers, the others through sum * (1 / area)
+            const bool two = t.box_area[which] == 4 && nx == 2;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dst[c] = round_u8(sum[c]);
+            for (int c = 0; c < 3; ++c)
+                dst[c] = two ? (uint8_t)(((int)sum[c] + 2) >> 2) : round_u8(sum[c] * t.box_scale[which]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c] = round_u8(sum[c]);
+        }
     } else {
         // bilinear kernel, area-mode coefficients: two source columns (the second pinned to the
         // last column), two source rows (the second clipped), 11-bit weights

@@ -439,7 +439,17 @@ static bool build_ego_axis(EgoTables &t, EgoAxis &ax, int ssize, int dsize, int 
     for (int d = 0; d < dsize; ++d) {
         ax.first[d] = pool;
         ax.count[d] = 0;
-        if (mode == kEgoArea) {
+        if (mode == kEgoBox) {
+            // integer factor: the destination pixel is the mean of `factor` whole source pixels
+            const int factor = ssize / dsize;
+            for (int k = 0; k < factor; ++k) {
+                if (pool >= kEgoTapPool || ax.count[d] >= 8) return false;   // kEgoMaxTaps of the kernel
+                t.tap_src[pool] = d * factor + k;
+                t.tap_w[pool] = 1.0f;
+                ++pool;
+                ++ax.count[d];
+            }
+        } else if (mode == kEgoArea) {
             const double fsx1 = d * scale, fsx2 = fsx1 + scale;
             const double cell = std::min(scale, ssize - fsx1);
             int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
@@ -505,12 +515,15 @@ int ssmap_set_egomap(ssmap_engine *eng, const ssmap_egomap_config *cfg) {
         const double sx = 1.0 / ((double)c.out_w / crop[w]), sy = 1.0 / ((double)c.out_h / crop[w]);
         if (sx >= 1 && sy >= 1) {
             const double eps = 2.220446049250313e-16;
-            if (std::fabs(sx - (int)sx) < eps && std::fabs(sy - (int)sy) < eps) {
-                eng->h_ego.clear();
-                return fail(SSMAP_ERR_UNSUPPORTED, "ego-map crops that are an integer multiple of egomap_size are not built "
-                                                   "(OpenCV takes its integer-factor area path there)");
-            }
             t.mode[w] = kEgoArea;
+            t.box_scale[w] = 1.0f;
+            t.box_area[w] = 1;
+            if (std::fabs(sx - (int)sx) < eps && std::fabs(sy - (int)sy) < eps) {
+                // OpenCV's integer-factor area path: sum of the block times 1 / area in float32
+                t.mode[w] = kEgoBox;
+                t.box_area[w] = (int)sx * (int)sy;
+                t.box_scale[w] = 1.0f / (float)t.box_area[w];
+            }
         } else {
             t.mode[w] = kEgoLinear;
         }

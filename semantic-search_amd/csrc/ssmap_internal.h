@@ -157,7 +157,7 @@ constexpr int kEgoMaxOut = 256;        // output side at most
 constexpr int kEgoTapPool = 16384;     // area-table entries of both crops and both axes
 constexpr int kEgoMaxRadius = 63;      // agent disk radius at most
 constexpr int kEgoPack = 16;           // envs per launch (their poses travel as a kernel argument)
-constexpr int kEgoArea = 0, kEgoLinear = 1;
+constexpr int kEgoArea = 0, kEgoLinear = 1, kEgoBox = 2;   // kEgoBox: integer shrink factors (plain box mean)
 
 // Per env and call: inverse rotation (OpenCV's inverted 2x3 matrix), crop origin, goal.
 struct EgoPose {
@@ -181,6 +181,8 @@ struct EgoAxis {
 struct EgoTables {
     int32_t side, origin, out_w, out_h;
     int32_t crop_off[2], mode[2];       // [0] small crop, [1] large crop
+    float box_scale[2];                 // kEgoBox: 1 / (factor_x * factor_y) in float32
+    int32_t box_area[2];                // kEgoBox: factor_x * factor_y
     int32_t agent_radius, aux_half, n_aux;
     int32_t aux_reach;                  // no auxiliary square reaches further from the centre than this
     int32_t agent_hw[kEgoMaxRadius + 1];

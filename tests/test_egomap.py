@@ -36,6 +36,17 @@ def test_resizes_keep_constant_images_constant():
     assert (eo.resize_nearest(unc, (128, 128)) == np.float32(0.25)).all()
 
 
+def test_integer_factor_area_resize_is_the_box_mean():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (384, 384, 3)).astype(np.uint8)
+    out = eo.resize_area_u8(img, (128, 128))                  # factor 3: sum * float32(1/9), rounded half even
+    blk = img[:3, :3].astype(np.int64).sum(axis=(0, 1))
+    assert np.array_equal(out[0, 0], np.rint(blk.astype(np.float32) * np.float32(1 / 9)).astype(np.uint8))
+    out2 = eo.resize_area_u8(img[:256, :256], (128, 128))     # factor 2: (sum + 2) >> 2
+    assert np.array_equal(out2[5, 7], (img[10:12, 14:16].astype(np.int64).sum(axis=(0, 1)) + 2) >> 2)
+    assert np.array_equal(eo.resize_area_u8(img[:128, :128], (128, 128)), img[:128, :128])   # factor 1
+
+
 def test_enlarging_area_mode_repeats_source_pixels_between_boundaries():
     """100 -> 128: destination pixels that lie inside one source pixel copy it exactly."""
     rng = np.random.default_rng(0)
@@ -74,8 +85,11 @@ def _random_maps(rng, rows, cols, palette, goal):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prob,large_side_m,with_aux", [(True, 10.0, True), (False, 10.0, False), (True, 15.0, False)])
-def test_engine_ego_maps_equal_the_restatement(prob, large_side_m, with_aux):
+@pytest.mark.parametrize("prob,large_side_m,with_aux,small_side_m", [
+    (True, 10.0, True, 3.0), (False, 10.0, False, 3.0), (True, 15.0, False, 3.0),
+    # crops that are 1, 2, 3 and 6 times the 128-pixel output: OpenCV's integer-factor area path
+    (True, 7.68, True, 3.84), (False, 11.52, False, 7.68), (True, 23.04, False, 3.0)])
+def test_engine_ego_maps_equal_the_restatement(prob, large_side_m, with_aux, small_side_m):
     import torch
     import semantic_search_amd as ssa
     rng = np.random.default_rng(11)
@@ -84,7 +98,7 @@ def test_engine_ego_maps_equal_the_restatement(prob, large_side_m, with_aux):
     n = len(bounds)
     eng = ssa.MapEngine(n, (48, 64), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
                         probablistic_mapping=prob, prob_aggregate="height_map_argmax", max_map_hw=(480, 480))
-    eng.set_egomap(egomap_large_side_m=large_side_m)
+    eng.set_egomap(egomap_small_side_m=small_side_m, egomap_large_side_m=large_side_m)
     palette = eng.color_pallete
     host = []
     for e in range(n):
@@ -115,7 +129,8 @@ def test_engine_ego_maps_equal_the_restatement(prob, large_side_m, with_aux):
         for e in range(n):
             sem, color, unc = host[e]
             want = eo.ego_map(sem, color, unc, poses[e][:3], poses[e][3:], bounds[e][:3], goals[e], palette,
-                              aux_angle_onehot=None if aux is None else aux[e], egomap_large_side_m=large_side_m)
+                              aux_angle_onehot=None if aux is None else aux[e], egomap_large_side_m=large_side_m,
+                              egomap_small_side_m=small_side_m)
             assert np.array_equal(small[e].cpu().numpy(), want[0]), (trial, e, "small")
             assert np.array_equal(large[e].cpu().numpy(), want[1]), (trial, e, "large")
             if prob:

@@ -321,3 +321,60 @@ def test_random_scenario_stubborn_rule(seed):
     for nm in ("cumulative_conf", "max_conf", "max_other_conf"):
         assert np.allclose(maps[nm].cpu().numpy(), getattr(ref, nm), rtol=1e-6, atol=1e-7, equal_nan=True), nm
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
+def test_random_rooms_goal_decay(seed):
+    """goal_decay on ray-cast rooms with a goal-class box: the box top is a blob of goal cells that
+    survives the erosion, so the dilated goal mask, the decay of the other cells and (with map
+    bounds that start inside the room) the wrapped twins are all in play.  Bit-exact.  (On the 96x128
+    and 120x160 frames goal cells survive the erosion in nearly every seed; the smaller frames are too
+    sparse for that and exercise the empty-mask shortcut instead.)"""
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(5000 + seed)
+    h, w = [(96, 128), (120, 160), (60, 80), (45, 67)][seed % 4]
+    c = 8
+    lut = scenes.small_lut(c)
+    filt = [None, 0.35][seed % 2]
+    # lower bound inside the room on some seeds: part of the room lies at negative cell indices
+    lower = np.array([rng.uniform(-0.5, 1.5), -0.2, rng.uniform(-0.5, 1.5)]) if seed % 3 else np.array([0.0, -0.2, 0.0])
+    bounds = np.concatenate([lower, lower + np.array([rng.uniform(3.5, 6.0), 2.7, rng.uniform(3.5, 6.0)])])
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_goal_decay", seg_model_n_classes=c, filter_goal_prob=filt)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(bounds, 0.03), **kw)
+    for o in (ref, eng.params):
+        o.goal_decay = 0.8931
+        o.goal_mark = 1.5408
+    eng.set_schema(lut)
+    ref.reset(bounds)
+    maps = eng.reset_env(0, bounds)
+    bx, bz = rng.uniform(1.9, 2.3, 2)
+    box = (bx, bz, bx + rng.uniform(0.5, 0.9), bz + rng.uniform(0.5, 0.9), rng.uniform(0.3, 0.6))
+    # the agent looks along (-sin yaw, -cos yaw): from the room's low corner towards the box
+    ax, az, yaw = rng.uniform(0.8, 1.2), rng.uniform(0.8, 1.2), np.pi + rng.uniform(0.6, 0.95)
+    for i in range(4):
+        agent, cam = scenes.make_pose(ax + 0.1 * i, 0.0, az + 0.1 * i, yaw + 0.03 * i)
+        frame = scenes.room_frame(rng, h, w, c, 1.0, cam, lut=lut, box=box, speckle=0.01, sharp=12.0)
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        raised = False
+        try:
+            found_ref = ref.update(obs)
+        except IndexError:
+            raised = True
+        eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 semantic=_dev(frame["semantic"][None], np.int32),
+                 semantic_unc=_dev(frame["semantic_unc"][None], np.float32),
+                 semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
+                 semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
+        found, status, n_upd = eng.results()
+        if raised or status[0]:
+            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+            eng.close()
+            return
+        assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
+        assert np.array_equal(maps["goal_map"].cpu().numpy(), ref.goal_map), f"frame {i}: goal_map"
+        assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map), f"frame {i}"
+    assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+    assert np.array_equal(maps["semantic_map_color"].cpu().numpy(), ref.semantic_map_color)
+    eng.close()

@@ -378,3 +378,71 @@ def test_random_rooms_goal_decay(seed):
     assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
     assert np.array_equal(maps["semantic_map_color"].cpu().numpy(), ref.semantic_map_color)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(30 * _SCALE))
+def test_random_rooms_found_decision(seed):
+    """Ray-cast rooms with a goal-class box and an agent that walks up to it: the found decision of
+    every frame (disk around the robot, entropy threshold or hit/view ratio) equals the oracle's,
+    labels bit-exact (probability rules: except where the two leading classes tie)."""
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(7000 + seed)
+    rule = ["height_map_log_odds", "height_map_avg_prob", "height_map_hv", "height_map_prob_hv",
+            "height_map_argmax", "height_map_w2_avg_prob"][seed % 6]
+    h, w = [(96, 128), (120, 160)][seed % 2]
+    c = 8
+    lut = scenes.small_lut(c)
+    lower = np.array([rng.uniform(-0.5, 0.8), -0.2, rng.uniform(-0.5, 0.8)]) if seed % 3 else np.array([0.0, -0.2, 0.0])
+    bounds = np.concatenate([lower, lower + np.array([rng.uniform(4.0, 6.0), 2.7, rng.uniform(4.0, 6.0)])])
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=c)
+    ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
+    eng = ssa.MapEngine(1, (h, w), max_map_hw=ssa.map_size(bounds, 0.03), **kw)
+    threshold = float(rng.uniform(0.2, 0.6))
+    for o in (ref, eng.params):
+        if "hv" in rule:
+            o.hv_min_views = 1
+            o.hv_ratio = 0.4
+        elif "argmax" not in rule:
+            o.entropy_threshold = threshold
+    eng.set_schema(lut)
+    ref.reset(bounds)
+    maps = eng.reset_env(0, bounds)
+    bx, bz = rng.uniform(1.9, 2.3, 2)
+    box = (bx, bz, bx + rng.uniform(0.5, 0.9), bz + rng.uniform(0.5, 0.9), rng.uniform(0.3, 0.6))
+    ax, az, yaw = rng.uniform(0.8, 1.1), rng.uniform(0.8, 1.1), np.pi + rng.uniform(0.65, 0.9)
+    prob_rule = "avg_prob" in rule or "log_odds" in rule
+    name = "log_odds_seg_map" if "log_odds" in rule else "avg_prob_seg_map"
+    seen = []
+    for i in range(5):
+        agent, cam = scenes.make_pose(ax + 0.15 * i, 0.0, az + 0.15 * i, yaw + 0.02 * i)
+        frame = scenes.room_frame(rng, h, w, c, 1.0, cam, lut=lut, box=box, speckle=0.01, sharp=12.0)
+        obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+        raised = False
+        try:
+            found_ref = ref.update(obs)
+        except IndexError:
+            raised = True
+        if prob_rule:
+            extra = dict(probs=_dev(frame["semantic_prob"][None], np.float32))
+        else:
+            extra = dict(semantic=_dev(frame["semantic"][None], np.int32),
+                         semantic_unc=_dev(frame["semantic_unc"][None], np.float32),
+                         semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32))
+        eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
+                 semantic_gt=_dev(frame["semantic_gt"][None], np.int32), **extra)
+        found, status, n_upd = eng.results()
+        if raised or status[0]:
+            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+            eng.close()
+            return
+        seen.append(bool(found_ref))
+        assert bool(found[0]) == bool(found_ref), f"frame {i}: found ({rule})"
+        sem = maps["semantic_map"].cpu().numpy().view(np.uint32)
+        bad = sem != ref.semantic_map
+        if prob_rule and bad.any():
+            top2 = np.sort(getattr(ref, name)[bad], axis=-1)[:, -2:]
+            assert (np.abs(top2[:, 1] - top2[:, 0]) <= 1e-4 * np.maximum(1.0, np.abs(top2[:, 1]))).all()
+        elif not prob_rule:
+            assert not bad.any(), f"frame {i}: semantic_map ({rule})"
+    eng.close()

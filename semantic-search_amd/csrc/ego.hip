@@ -16,7 +16,8 @@
 
 namespace ssmap {
 
-constexpr int kEgoMaxTaps = 8;     // area-table taps per output pixel and axis (shrink factors below 7)
+// area-table taps per output pixel and axis: the kernel is built for 8 (shrink factors below 7,
+// the usual crops) and for 32 (up to the host's limit of kEgoTapLimit taps)
 
 // What rot_pixel needs besides the tables: kept in LDS / registers by the kernel.
 struct EgoView {
@@ -99,6 +100,7 @@ __device__ inline uint8_t round_u8(float v) {
 }
 
 // grid: (ceil(out_w * out_h / 256), 2 maps, envs of this launch)
+template <int kEgoMaxTaps>
 __global__ __launch_bounds__(256) void k_ego_maps(View v, EgoPack pack, int env0, const EgoTables *tables,
                                                   uint8_t *ego_small, uint8_t *ego_large, float *unc_small,
                                                   float *unc_large) {
@@ -229,8 +231,13 @@ void launch_ego_maps(const View &v, const EgoPose *host_poses, const EgoTables *
         const int n = v.E - env0 < kEgoPack ? v.E - env0 : kEgoPack;
         EgoPack pack;
         for (int i = 0; i < n; ++i) pack.p[i] = host_poses[env0 + i];
-        hipLaunchKernelGGL(k_ego_maps, dim3((n_pix + 255) / 256, 2, n), dim3(256), 0, s, v, pack, env0, d_tables,
-                           ego_small, ego_large, unc_small, unc_large);
+        const dim3 grid((n_pix + 255) / 256, 2, n);
+        if (h_tables.max_taps <= 8)
+            hipLaunchKernelGGL((k_ego_maps<8>), grid, dim3(256), 0, s, v, pack, env0, d_tables,
+                               ego_small, ego_large, unc_small, unc_large);
+        else
+            hipLaunchKernelGGL((k_ego_maps<kEgoTapLimit>), grid, dim3(256), 0, s, v, pack, env0, d_tables,
+                               ego_small, ego_large, unc_small, unc_large);
     }
 }
 

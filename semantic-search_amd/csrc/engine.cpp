@@ -443,7 +443,7 @@ static bool build_ego_axis(EgoTables &t, EgoAxis &ax, int ssize, int dsize, int 
             // integer factor: the destination pixel is the mean of `factor` whole source pixels
             const int factor = ssize / dsize;
             for (int k = 0; k < factor; ++k) {
-                if (pool >= kEgoTapPool || ax.count[d] >= 8) return false;   // kEgoMaxTaps of the kernel
+                if (pool >= kEgoTapPool || ax.count[d] >= kEgoTapLimit) return false;
                 t.tap_src[pool] = d * factor + k;
                 t.tap_w[pool] = 1.0f;
                 ++pool;
@@ -457,7 +457,7 @@ static bool build_ego_axis(EgoTables &t, EgoAxis &ax, int ssize, int dsize, int 
             sx1 = std::min(sx1, sx2);
             auto push = [&](int si, double w) {
                 if (pool >= kEgoTapPool) return false;
-                if (ax.count[d] >= 8) return false;   // kEgoMaxTaps of the kernel
+                if (ax.count[d] >= kEgoTapLimit) return false;
                 t.tap_src[pool] = si;
                 t.tap_w[pool] = (float)w;
                 ++pool;
@@ -533,6 +533,11 @@ int ssmap_set_egomap(ssmap_engine *eng, const ssmap_egomap_config *cfg) {
             return fail(SSMAP_ERR_UNSUPPORTED, "ego-map crops too large for the resize tables");
         }
     }
+    t.max_taps = 0;
+    for (int w = 0; w < 2; ++w)
+        for (int a = 0; a < 2; ++a)
+            if (t.mode[w] != kEgoLinear)
+                for (int d = 0; d < (a ? c.out_h : c.out_w); ++d) t.max_taps = std::max(t.max_taps, t.axis[w][a].count[d]);
     if (!eng->d_ego) {
         int rc = dev_alloc(&eng->d_ego, (size_t)1);
         if (rc != SSMAP_OK) return rc;

@@ -156,6 +156,7 @@ __host__ __device__ inline double unorder_f64(unsigned long long k) {
 constexpr int kEgoMaxOut = 256;        // output side at most
 constexpr int kEgoTapPool = 16384;     // area-table entries of both crops and both axes
 constexpr int kEgoMaxRadius = 63;      // agent disk radius at most
+constexpr int kEgoTapLimit = 32;       // area-table taps per output pixel and axis at most (shrink factors up to 30)
 constexpr int kEgoPack = 16;           // envs per launch (their poses travel as a kernel argument)
 constexpr int kEgoArea = 0, kEgoLinear = 1, kEgoBox = 2;   // kEgoBox: integer shrink factors (plain box mean)
 
@@ -185,6 +186,7 @@ struct EgoTables {
     int32_t box_area[2];                // kEgoBox: factor_x * factor_y
     int32_t agent_radius, aux_half, n_aux;
     int32_t aux_reach;                  // no auxiliary square reaches further from the centre than this
+    int32_t max_taps;                   // largest tap count of any output pixel and axis
     int32_t agent_hw[kEgoMaxRadius + 1];
     int32_t aux_points[2 * SSMAP_MAX_AUX];
     uint8_t active_goal_color[4], arrow_color[4];

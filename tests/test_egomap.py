@@ -197,3 +197,56 @@ def test_engine_ego_maps_more_envs_than_one_launch_takes():
         assert np.array_equal(small[e].cpu().numpy(), want[0]) and np.array_equal(large[e].cpu().numpy(), want[1]), e
         assert np.array_equal(unc_s[e].cpu().numpy(), want[2]) and np.array_equal(unc_l[e].cpu().numpy(), want[3]), e
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_engine_ego_maps_random_configurations(seed):
+    """Random crop sizes (shrinking, enlarging and integer factors), output sizes (square or not),
+    agent radii, auxiliary bins, map sizes smaller and larger than the crops, poses inside and
+    outside of the map: the kernel equals the restatement bit for bit."""
+    import torch
+    import semantic_search_amd as ssa
+    rng = np.random.default_rng(900 + seed)
+    prob = bool(seed % 2)
+    small_m = float(rng.choice([1.5, 2.0, 3.0, 3.84, 4.5]))
+    large_m = float(rng.choice([6.0, 7.68, 10.0, 12.5, 16.0]))
+    size = [(128, 128), (64, 64), (96, 128), (100, 100), (128, 80)][seed % 5]
+    radius_m = float(rng.choice([0.06, 0.1, 0.25]))
+    bins = int(rng.choice([8, 12]))
+    offset = int(rng.choice([0, 60, 150]))
+    cfg = dict(egomap_small_side_m=small_m, egomap_large_side_m=large_m, egomap_size=size,
+               agent_draw_radius_m=radius_m, aux_num_bins=bins, offset_for_cut=offset)
+    bounds = np.array([rng.uniform(-2, 1), 0.0, rng.uniform(-2, 1), 0, 2.5, 0])
+    bounds[3] = bounds[0] + rng.uniform(2.0, 13.0)
+    bounds[5] = bounds[2] + rng.uniform(2.0, 13.0)
+    eng = ssa.MapEngine(1, (48, 64), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+                        probablistic_mapping=prob, prob_aggregate="height_map_argmax", max_map_hw=(480, 480))
+    eng.set_egomap(**cfg)
+    palette = eng.color_pallete
+    maps = eng.reset_env(0, bounds)
+    rows, cols = maps["semantic_map"].shape
+    sem, color, unc = _random_maps(rng, rows, cols, palette, 3)
+    maps["semantic_map"].copy_(torch.from_numpy(sem.view(np.int32)))
+    maps["semantic_map_color"].copy_(torch.from_numpy(color))
+    if prob:
+        maps["unc_map"].copy_(torch.from_numpy(unc))
+    for trial in range(3):
+        fx, fz = rng.uniform(-0.15, 1.15, 2)
+        pos = np.array([bounds[0] + fx * (bounds[3] - bounds[0]), 0.1, bounds[2] + fz * (bounds[5] - bounds[2])])
+        pose = np.concatenate([pos, _yaw_quat(rng.uniform(-math.pi, math.pi))])
+        goal = int(rng.integers(3, 9))
+        aux = None
+        if trial != 1:
+            aux = np.zeros((1, bins), dtype=np.float32)
+            aux[0, rng.integers(0, bins)] = 1.0
+        small, large, unc_s, unc_l = eng.ego_maps(pose[None], [goal], aux)
+        torch.cuda.synchronize()
+        want = eo.ego_map(sem, color, unc if prob else None, pose[:3], pose[3:], bounds[:3], goal, palette,
+                          aux_angle_onehot=None if aux is None else aux[0], **cfg)
+        assert np.array_equal(small[0].cpu().numpy(), want[0]), (trial, "small", cfg)
+        assert np.array_equal(large[0].cpu().numpy(), want[1]), (trial, "large", cfg)
+        if prob:
+            assert np.array_equal(unc_s[0].cpu().numpy(), want[2]), (trial, "unc small", cfg)
+            assert np.array_equal(unc_l[0].cpu().numpy(), want[3]), (trial, "unc large", cfg)
+    eng.close()

@@ -584,3 +584,45 @@ def test_update_map_takes_torch_tensors_like_numpy_arrays():
             assert np.array_equal(a, b)
     for name in ("semantic_map", "height_map", "gt_map", "log_odds_seg_map", "unc_map", "semantic_map_color"):
         assert np.array_equal(getattr(mappers[0], name), getattr(mappers[1], name), equal_nan=True), name
+
+
+@pytest.mark.parametrize("rule", ["height_map_log_odds", "height_map_prob_hv", "height_map_goal_decay"])
+def test_mapper_episodes_with_different_map_bounds(rule):
+    """One SemanticMapper over three episodes, like an env that resets it per scene (env.py:377):
+    a small map, a larger one (the engine is rebuilt for it), then a small one again.  After every
+    frame of every episode the maps equal those of an oracle that was reset the same way: nothing
+    of an earlier episode (overlay lists, trail, per-step scratch) leaks into the next."""
+    import semantic_search_amd as ssa
+    lut = scenes.small_lut(8)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=8)
+    m = ssa.SemanticMapper(**kw)
+    m.map_seg_to_schema = lambda ids: lut[ids]
+    ref = mo.OracleMapper(schema_lut=lut, **kw)
+    for o in (m, ref):
+        if "hv" in rule:
+            o.hv_min_views, o.hv_ratio = 1, 0.4
+    rng = np.random.default_rng(21)
+    episodes = [np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5]), np.array([-1.5, -0.2, -2.0, 6.5, 2.5, 7.0]),
+                np.array([0.4, -0.2, 0.3, 4.0, 2.5, 4.2])]
+    for ep, bounds in enumerate(episodes):
+        m.reset(bounds)
+        ref.reset(bounds)
+        for i in range(4):
+            agent, cam = scenes.make_pose(1.0 + 0.2 * i, 0.0, 1.0 + 0.2 * i, np.pi + 0.75 + 0.05 * ep)
+            frame = scenes.room_frame(rng, 96, 128, 8, 1.0, cam, lut=lut, box=(2.0, 2.0, 2.9, 2.8, 0.5),
+                                      speckle=0.01, sharp=12.0)
+            obs = scenes.make_obs(frame, agent, cam, goal_index=0)
+            want_found = ref.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in obs.items()})
+            _, found = m.update_map(obs)
+            assert bool(found) == bool(want_found), (ep, i, "found")
+            assert m.semantic_map.shape == ref.semantic_map.shape
+            assert np.array_equal(m.semantic_map, ref.semantic_map), (ep, i, "semantic_map")
+            assert np.array_equal(m.semantic_map_color, ref.semantic_map_color), (ep, i, "colour")
+            assert np.array_equal(m.height_map, ref.height_map), (ep, i, "height_map")
+            if "hv" in rule:
+                assert np.array_equal(m.hits, ref.hits) and np.array_equal(m.views, ref.views), (ep, i)
+            if "goal_decay" in rule:
+                assert np.array_equal(m.goal_map, ref.goal_map), (ep, i, "goal_map")
+            if "log_odds" in rule:
+                _close(m.log_odds_seg_map, ref.log_odds_seg_map, "log_odds_seg_map", rtol=2e-5, atol=2e-5)

@@ -626,3 +626,61 @@ def test_mapper_episodes_with_different_map_bounds(rule):
                 assert np.array_equal(m.goal_map, ref.goal_map), (ep, i, "goal_map")
             if "log_odds" in rule:
                 _close(m.log_odds_seg_map, ref.log_odds_seg_map, "log_odds_seg_map", rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rule", ["height_map_prob_hv", "height_map_avg_prob", "height_map_goal_decay"])
+def test_one_env_of_a_batch_is_reset_while_the_others_go_on(rule):
+    """Vectorised envs end their episodes at different times: env 1 of three is reset (new bounds)
+    after two steps while envs 0 and 2 keep their maps.  Every env equals an engine of its own that
+    saw the same frames and the same reset."""
+    import semantic_search_amd as ssa
+    h, w, c, n_envs = 96, 128, 8, 3
+    lut = scenes.small_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=c)
+    bounds = [np.array([0, 0, 0, 4.5, 2.5, 4.5]), np.array([-1.0, 0, -2.0, 5.0, 2.5, 3.1]),
+              np.array([0.3, 0, 0.2, 3.0, 2.5, 6.0])]
+    new_bounds = np.array([0.5, 0, 0.5, 5.5, 2.5, 5.0])
+    big = ssa.MapEngine(n_envs, (h, w), max_map_hw=(220, 220), **kw)
+    big.set_schema(lut)
+    singles = []
+    for e in range(n_envs):
+        big.reset_env(e, bounds[e])
+        s = ssa.MapEngine(1, (h, w), max_map_hw=(220, 220), **kw)
+        s.set_schema(lut)
+        s.reset_env(0, bounds[e])
+        singles.append(s)
+    for o in [big.params] + [s.params for s in singles]:
+        o.hv_min_views, o.hv_ratio = 1, 0.4
+    rng = np.random.default_rng(4)
+    prob_rule = "avg_prob" in rule
+    for i in range(5):
+        if i == 2:
+            big.reset_env(1, new_bounds)
+            singles[1].reset_env(0, new_bounds)
+        frames, ag, cam = [], [], []
+        for e in range(n_envs):
+            a, cm = scenes.make_pose(1.0 + 0.2 * i, 0.0, 1.0 + 0.15 * i + 0.1 * e, np.pi + 0.75)
+            frames.append(scenes.room_frame(rng, h, w, c, 1.0, cm, lut=lut, box=(2.0, 2.0, 2.9, 2.8, 0.5),
+                                            speckle=0.01, sharp=12.0))
+            ag.append(a)
+            cam.append(cm)
+        stack = lambda key, dt: np.stack([f[key] for f in frames]).astype(dt)
+        def feed(eng, sl, goals):
+            kwargs = dict(semantic_gt=_to_dev(stack("semantic_gt", np.int32)[sl], np.int32))
+            if prob_rule:
+                kwargs["probs"] = _to_dev(stack("semantic_prob", np.float32)[sl], np.float32)
+            else:
+                for key, dt in (("semantic", np.int32), ("semantic_unc", np.float32), ("semantic_max_prob", np.float32)):
+                    kwargs[key] = _to_dev(stack(key, dt)[sl], dt)
+            eng.step(_to_dev(stack("depth", np.float32)[sl], np.float32), np.stack(ag)[sl], np.stack(cam)[sl], goals, **kwargs)
+            return eng.results()
+        fb, sb, nb = feed(big, slice(0, n_envs), [3] * n_envs)
+        for e in range(n_envs):
+            f1, s1_, n1 = feed(singles[e], slice(e, e + 1), [3])
+            assert (fb[e], sb[e], nb[e]) == (f1[0], s1_[0], n1[0]), (i, e)
+            for nm, t in big.maps[e].items():
+                assert torch.equal(t, singles[e].maps[0][nm]), (i, e, nm)
+    big.close()
+    for s in singles:
+        s.close()

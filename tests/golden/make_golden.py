@@ -42,6 +42,7 @@ def load_reference():
 
 
 # ----------------------------------------------------------------------------- cases
+SCHEMA41_LUT = [0, 1, 2, 3, 11, 14, 18, 22, 10, 5, 30, 40]   # model class -> id of the 41-class schema
 ROOM = dict(room=(0.0, 0.0, 4.5, 4.5), box=(2.6, 2.6, 3.3, 3.2, 0.7))
 BOUNDS = [0.0, -0.2, 0.0, 4.5, 2.5, 4.5]
 YAW_IN = np.pi + 0.75      # from (1,1) towards the box at ~(3,3)
@@ -111,6 +112,17 @@ CASES = [
     dict(name="argmax_collect_nb", rule="height_map_argmax", prob=True, C=8, hw=(60, 80),
          frames=4, scene="room", start=(1.0, 1.0), step=0.5, yaw=YAW_IN,
          collect=True, goal_classes={3: [3]}),
+    # the reference's 41- and 38-class schemas: goal ids 3, 11, 14, 18, 22, 10 (mapper.py:140-143),
+    # no occupancy override, palette and path id sized by the schema
+    dict(name="schema41_hv", rule="height_map_hv", prob=True, C=12, hw=(48, 64), n_schema=41, goal_index=2,
+         lut=SCHEMA41_LUT, frames=4, scene="uniform", start=(2.2, 2.2), step=0.1, yaw=1.1, turn=-0.4,
+         attrs=dict(hv_min_views=1, hv_ratio=0.3)),
+    dict(name="schema41_avg_prob", rule="height_map_avg_prob", prob=True, C=12, hw=(48, 64), n_schema=41,
+         goal_index=1, lut=SCHEMA41_LUT, frames=4, scene="uniform", start=(2.2, 2.2), step=0.1, yaw=0.3, turn=0.5,
+         attrs=dict(entropy_threshold=0.9)),
+    dict(name="schema38_argmax_filter", rule="height_map_argmax", prob=True, C=12, hw=(48, 64), n_schema=38,
+         goal_index=5, lut=SCHEMA41_LUT[:11] + [37], frames=4, scene="uniform", start=(2.2, 2.2), step=0.1,
+         yaw=2.0, turn=0.3, filter_goal_prob=0.3),
     dict(name="uniform_goal_decay", rule="height_map_goal_decay", prob=True, C=6, hw=(48, 64),
          frames=3, scene="uniform", start=(2.2, 2.2), step=0.0, yaw=2.0, turn=0.5,
          filter_goal_prob=0.3),
@@ -125,6 +137,8 @@ def build_frames(case):
     lut = None
     if c:
         lut = scenes.schema_lut(c) if c >= 37 else scenes.small_lut(c)
+    if "lut" in case:
+        lut = np.array(case["lut"], dtype=np.int64)
     poses = []
     yaw = case["yaw"]
     for i in range(case["frames"]):
@@ -182,7 +196,7 @@ def run_case(ref, case):
         kw["collect_nb_data"] = True
     try:
         mapper = ref.SemanticMapper(
-            num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+            num_semantic_classes=case.get("n_schema", 9), depth_hfov=59.0, depth_range=(0.5, 5.0),
             probablistic_mapping=case["prob"], prob_aggregate=case["rule"],
             seg_model_n_classes=c or None, filter_goal_prob=case.get("filter_goal_prob"), **kw)
     finally:
@@ -201,6 +215,7 @@ def run_case(ref, case):
                 hw=list(case["hw"]), n_frames=len(frames), bounds=BOUNDS,
                 filter_goal_prob=case.get("filter_goal_prob"), attrs=case.get("attrs", {}),
                 collect_nb_data=bool(case.get("collect")),
+                n_schema=case.get("n_schema", 9), goal_index=case.get("goal_index", 0),
                 goal_classes={str(k): list(v) for k, v in case.get("goal_classes", {}).items()},
                 nb_models=None if nb_models is None else {
                     str(g): dict(classes_=[int(v) for v in m.classes_],
@@ -211,7 +226,7 @@ def run_case(ref, case):
                 lut=None if lut is None else [int(v) for v in lut],
                 numpy=np.__version__)
     for i, (fr, agent, cam) in enumerate(frames):
-        obs = scenes.make_obs(fr, agent, cam, goal_index=0)
+        obs = scenes.make_obs(fr, agent, cam, goal_index=case.get("goal_index", 0))
         # keep only the observation keys this rule reads (mapper.py:361-727)
         uses_probs = any(t in case["rule"] for t in ("avg_prob", "log_odds"))
         keeps_probs = bool(case.get("nb") or case.get("collect"))   # goal statistics read semantic_prob
@@ -292,7 +307,10 @@ def main():
     ref = load_reference()
     check_rotation_seam(ref)
     total = 0
+    only = set(sys.argv[1:])          # case names; none = all
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         out = run_case(ref, case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)

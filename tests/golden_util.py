@@ -31,7 +31,7 @@ class GoldenCase:
 
     def mapper_kwargs(self):
         m = self.meta
-        kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
+        kw = dict(num_semantic_classes=m.get("n_schema", 9), depth_hfov=59.0, depth_range=(0.5, 5.0),
                   probablistic_mapping=m["prob"], prob_aggregate=m["rule"],
                   seg_model_n_classes=m["C"] or None, filter_goal_prob=m["filter_goal_prob"])
         if m.get("collect_nb_data"):
@@ -54,7 +54,7 @@ class GoldenCase:
         obs = {k[len(pre):]: self.data[k].copy() for k in self.data.files if k.startswith(pre)}
         obs["agent_position_and_rotation"] = obs.pop("agent")
         obs["camera_position_and_rotation"] = obs.pop("camera")
-        obs["objectgoal"] = np.array([0])
+        obs["objectgoal"] = np.array([self.meta.get("goal_index", 0)])
         return obs
 
     def expect(self, i, key):

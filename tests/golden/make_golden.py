@@ -123,6 +123,17 @@ CASES = [
     dict(name="schema38_argmax_filter", rule="height_map_argmax", prob=True, C=12, hw=(48, 64), n_schema=38,
          goal_index=5, lut=SCHEMA41_LUT[:11] + [37], frames=4, scene="uniform", start=(2.2, 2.2), step=0.1,
          yaw=2.0, turn=0.3, filter_goal_prob=0.3),
+    # constructor parameters away from their defaults: cell size, height cut-off, found distance,
+    # field of view, depth range (mapper.py:49-76)
+    dict(name="ctor_variant_log_odds", rule="height_map_log_odds", prob=True, C=8, hw=(96, 128),
+         frames=5, scene="room", start=(1.0, 1.0), step=0.3, yaw=YAW_IN, speckle=0.01, sharp=12.0,
+         box=(2.0, 2.0, 2.9, 2.8, 0.5), hfov=79.0, depth_range=(0.3, 4.0),
+         ctor=dict(pixel2meter=0.05, height_cutoff_m=0.3, success_dist_m=0.6), attrs=dict(entropy_threshold=0.4)),
+    dict(name="ctor_variant_hv", rule="height_map_hv", prob=True, C=8, hw=(60, 80),
+         frames=5, scene="room", start=(1.0, 1.0), step=0.3, yaw=YAW_IN, speckle=0.01, sharp=12.0,
+         box=(2.0, 2.0, 2.9, 2.8, 0.5), hfov=45.0, depth_range=(0.4, 3.5),
+         ctor=dict(pixel2meter=0.02, height_cutoff_m=-0.2, success_dist_m=1.5),
+         attrs=dict(hv_min_views=1, hv_ratio=0.3)),
     dict(name="uniform_goal_decay", rule="height_map_goal_decay", prob=True, C=6, hw=(48, 64),
          frames=3, scene="uniform", start=(2.2, 2.2), step=0.0, yaw=2.0, turn=0.5,
          filter_goal_prob=0.3),
@@ -156,7 +167,8 @@ def build_frames(case):
                 room["box"] = case["box"]
             fr = scenes.room_frame(rng, h, w, c, temp, cam, lut=lut, sharp=case.get("sharp", 6.0),
                                    speckle=case.get("speckle", 0.03),
-                                   quantum=case.get("quantum"), **room)
+                                   quantum=case.get("quantum"), hfov_deg=case.get("hfov", 59.0),
+                                   depth_range=tuple(case.get("depth_range", (0.5, 5.0))), **room)
         frames.append((fr, agent, cam))
     return frames, lut
 
@@ -196,9 +208,11 @@ def run_case(ref, case):
         kw["collect_nb_data"] = True
     try:
         mapper = ref.SemanticMapper(
-            num_semantic_classes=case.get("n_schema", 9), depth_hfov=59.0, depth_range=(0.5, 5.0),
+            num_semantic_classes=case.get("n_schema", 9), depth_hfov=case.get("hfov", 59.0),
+            depth_range=tuple(case.get("depth_range", (0.5, 5.0))),
             probablistic_mapping=case["prob"], prob_aggregate=case["rule"],
-            seg_model_n_classes=c or None, filter_goal_prob=case.get("filter_goal_prob"), **kw)
+            seg_model_n_classes=c or None, filter_goal_prob=case.get("filter_goal_prob"),
+            **case.get("ctor", {}), **kw)
     finally:
         if case.get("nb"):
             ref.pickle.load = real_load
@@ -216,6 +230,8 @@ def run_case(ref, case):
                 filter_goal_prob=case.get("filter_goal_prob"), attrs=case.get("attrs", {}),
                 collect_nb_data=bool(case.get("collect")),
                 n_schema=case.get("n_schema", 9), goal_index=case.get("goal_index", 0),
+                hfov=case.get("hfov", 59.0), depth_range=list(case.get("depth_range", (0.5, 5.0))),
+                ctor=case.get("ctor", {}),
                 goal_classes={str(k): list(v) for k, v in case.get("goal_classes", {}).items()},
                 nb_models=None if nb_models is None else {
                     str(g): dict(classes_=[int(v) for v in m.classes_],

@@ -31,9 +31,11 @@ class GoldenCase:
 
     def mapper_kwargs(self):
         m = self.meta
-        kw = dict(num_semantic_classes=m.get("n_schema", 9), depth_hfov=59.0, depth_range=(0.5, 5.0),
+        kw = dict(num_semantic_classes=m.get("n_schema", 9), depth_hfov=m.get("hfov", 59.0),
+                  depth_range=tuple(m.get("depth_range", (0.5, 5.0))),
                   probablistic_mapping=m["prob"], prob_aggregate=m["rule"],
                   seg_model_n_classes=m["C"] or None, filter_goal_prob=m["filter_goal_prob"])
+        kw.update(m.get("ctor", {}))
         if m.get("collect_nb_data"):
             kw["collect_nb_data"] = True
         if m.get("nb_models"):

@@ -6,8 +6,10 @@ Restates the tail of the reference's segmentation wrappers with torch CPU tensor
 (both do: logits / T -> softmax over the class axis -> normalised entropy with a 1e-6
 epsilon -> max / argmax -> schema LUT -> goal-class probability pooling).
 
-Parity UNPINNED: the reference holds no test vector for this tail and infer.py cannot be
-imported here (its model dependencies are absent); this file follows its text.
+Pinned: tests/golden/stage1/*.npz were recorded from those two predict() methods themselves (the
+reference's infer.py executed in the build container on synthetic network outputs, its absent
+model dependencies replaced by inert import shims: tests/golden/make_stage1_golden.py);
+tests/test_stage1_golden.py checks that this file reproduces them bit for bit.
 """
 from __future__ import annotations
 

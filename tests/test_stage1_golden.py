@@ -1,0 +1,70 @@
+"""Stage 1 against vectors recorded from the reference's own predict() tails
+(tests/golden/make_stage1_golden.py ran EmsanetWrapper.predict and SegformerWrapper.predict of
+sem_objnav/segment/infer.py on synthetic network outputs; tests/golden/stage1/*.npz).
+
+CPU: the restatement (oracle/stage1_oracle.py) reproduces them bit for bit, and the class tables
+the tests build their schema LUTs from are the reference's.  GPU: the HIP stage-1 kernels, through
+the C ABI, within rtol 1e-5 for the floats and exactly for the labels."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import stage1_oracle as s1
+from tests import scenes
+
+DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage1")
+NAMES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(DIR, "*.npz")))
+
+
+def _load(name):
+    data = np.load(os.path.join(DIR, name + ".npz"))
+    return data, json.loads(str(data["meta"]))
+
+
+def test_there_are_stage1_vectors():
+    assert len(NAMES) >= 5
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_the_reference_tail(name):
+    data, meta = _load(name)
+    assert np.array_equal(scenes.schema_lut(meta["C"]), data["lut"]), "the tests' class table is not the reference's"
+    with np.errstate(all="ignore"):
+        got = s1.predict_tail(data["logits"], meta["temperature"], data["lut"], table_order=meta["table_order"])
+    assert np.array_equal(got["semantic"], data["semantic"])
+    for key in ("semantic_prob", "semantic_unc", "semantic_max_prob"):
+        assert np.array_equal(got[key], data[key], equal_nan=True), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_engine_stage1_matches_the_reference_tail(name):
+    import torch
+    import semantic_search_amd as ssa
+    data, meta = _load(name)
+    logits = data["logits"]
+    c, h, w = logits.shape
+    eng = ssa.MapEngine(1, (h, w), depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+                        prob_aggregate="height_map_argmax", seg_model_n_classes=c, max_map_hw=(100, 100))
+    eng.set_schema(data["lut"])
+    out = eng.stage1(torch.from_numpy(logits[None].copy()).cuda(), meta["temperature"], want_probs=True)
+    torch.cuda.synchronize()
+    probs = out["semantic_prob"][0].cpu().numpy().astype(np.float64)
+    want = data["semantic_prob"].astype(np.float64)
+    assert np.isfinite(probs).all()
+    assert (np.abs(probs - want) <= 1e-9 + 1e-5 * np.abs(want)).all(), np.abs(probs - want).max()
+    unc, want_unc = out["semantic_unc"][0].cpu().numpy(), data["semantic_unc"]
+    assert (np.abs(unc - want_unc) <= 2e-6 + 1e-5 * np.abs(want_unc)).all(), np.abs(unc - want_unc).max()
+    sem = out["semantic"][0].cpu().numpy()
+    bad = sem != data["semantic"]
+    if bad.any():   # only where the two leading probabilities tie to within rounding
+        top2 = np.sort(np.moveaxis(data["semantic_prob"], 0, -1)[bad], axis=-1)[:, -2:]
+        assert (top2[:, 1] - top2[:, 0] < 1e-5).all()
+    assert not bad[:4].any(), "the constructed rows (ties, saturation, masked classes) have exact answers"
+    ok = ~bad
+    maxp, want_maxp = out["semantic_max_prob"][0].cpu().numpy(), data["semantic_max_prob"]
+    assert (np.abs(maxp - want_maxp)[ok] <= 1e-7 + 1e-5 * np.abs(want_maxp[ok])).all()
+    eng.close()

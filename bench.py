@@ -157,11 +157,17 @@ def main():
         n_procs = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
         cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 10)
     dist = None
+    # RCCL between the ranks of a node; SSMAP_BENCH_BACKEND=gloo lets several ranks share one GPU
+    # (a rehearsal of the multi-rank path on a one-GPU box: RCCL refuses two ranks on one device)
+    backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(device)
 
     import semantic_search_amd as ssa
@@ -217,9 +223,10 @@ def main():
     stage_ms, n_prof = eng.profile_read()
     found, status, n_upd = eng.results()
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    red_dev = device if backend == "nccl" else torch.device("cpu")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     metric = torch.tensor([float(args.steps * E), float(found.sum()), float(n_upd.sum())],
-                          dtype=torch.float64, device=device)
+                          dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(metric, op=dist.ReduceOp.SUM)   # the path's only exchange: final metric sum

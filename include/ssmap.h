@@ -7,7 +7,9 @@
  * method (file:line) whose work it takes over.  A Python host (ctypes) owns every map
  * array as a device tensor and passes plain pointers; the engine allocates only its own
  * per-frame scratch in ssmap_create().  No entry point throws; all return an
- * ssmap_status code.  Nothing here synchronises the stream except ssmap_read_results().
+ * ssmap_status code.  Of the per-step calls only ssmap_read_results(), ssmap_profile_read() and
+ * ssmap_path_append() wait for the stream; the set-up calls (ssmap_set_*, ssmap_bind_env) copy
+ * on the null stream and expect the engine's streams to be idle.
  *
  * Layouts (all row-major, little-endian, device memory unless marked HOST):
  *   frames   depth [E][H][W] f32 (mutated in place), logits/probs [E][C][H][W] f32,
@@ -159,7 +161,10 @@ int ssmap_set_nb_model(ssmap_engine *eng, int32_t goal_sem_id, int32_t n_classes
                        const int32_t *classes, const double *class_log_prior,
                        const double *norm_const, const double *theta, const double *var);
 
-/* SemanticMapper.reset (mapper.py:193-269) for env `e`: binds freshly initialised maps. */
+/* SemanticMapper.reset (mapper.py:193-269) for env `e`: binds freshly initialised maps.
+ * Like ssmap_set_schema / ssmap_set_palette / ssmap_set_nb_model / ssmap_set_egomap it updates
+ * engine state with blocking copies on the null stream: the caller must have drained every
+ * stream that still runs a step of this engine (hipStreamSynchronize) before calling it. */
 int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps);
 
 /* SemanticMapper.update_map for all E envs, without the ego-map rendering

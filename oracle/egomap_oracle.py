@@ -27,7 +27,7 @@ import math
 import numpy as np
 
 from oracle import raster
-from oracle.mapper_oracle import quat_to_matrix
+from oracle.mapper_oracle import quat_from_rotvec, quat_mul, quat_to_matrix
 
 AB_BITS = 10
 AB_SCALE = 1 << AB_BITS
@@ -237,8 +237,11 @@ def resize_nearest(src, dsize_wh):
 
 # ----------------------------------------------------------------------------- the method
 def heading_angle(agent_quat_wxyz):
-    """phi of mapper.py:885-890: polar angle of the agent's forward axis in the x/z plane."""
-    R = quat_to_matrix(np.asarray(agent_quat_wxyz, dtype=np.float64))
+    """phi of mapper.py:885-890: polar angle, in the x/z plane, of (0, 0, 1) rotated by the agent
+    rotation update_map hands to ego_map, which is the pose quaternion times a half turn about y
+    (mapper.py:291-293, 840-847)."""
+    q = quat_mul(np.asarray(agent_quat_wxyz, dtype=np.float64), quat_from_rotvec(0.0, math.pi, 0.0))
+    R = quat_to_matrix(q)
     heading = R @ np.array([0.0, 0.0, 1.0])
     return math.atan2(heading[2], heading[0])
 

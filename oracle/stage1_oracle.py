@@ -26,8 +26,9 @@ def pooling_groups(lut, table_order=None):
     return {g: [k for k in order if lut[k] == g] for g in range(3, 9)}
 
 
-def predict_tail(logits: np.ndarray, temperature: float, lut, table_order=None):
-    """logits (C,H,W) float32 -> dict with the reference's predict() keys."""
+def predict_tail(logits: np.ndarray, temperature: float, lut, table_order=None, pool_groups=None):
+    """logits (C,H,W) float32 -> dict with the reference's predict() keys.  `pool_groups`
+    ({goal id: model classes}) stands for objnav2pred when it is not the table's inverse."""
     lut = np.asarray(lut)
     with torch.no_grad():
         z = torch.from_numpy(np.ascontiguousarray(logits)) / temperature
@@ -37,7 +38,10 @@ def predict_tail(logits: np.ndarray, temperature: float, lut, table_order=None):
     semantic = lut[arg.numpy()].astype(np.int32)
     max_probs = max_probs.numpy().copy()
     probs = prob.numpy()
-    for gid, members in pooling_groups(lut, table_order).items():
+    groups = pooling_groups(lut, table_order)
+    if pool_groups is not None:
+        groups = {g: list(pool_groups.get(g, [])) for g in range(3, 9)}
+    for gid, members in groups.items():
         mask = semantic == gid
         max_probs[mask] = probs[members, :].sum(axis=0)[mask]
     return {"semantic": semantic, "semantic_max_prob": max_probs, "semantic_prob": probs,

@@ -95,6 +95,12 @@ int dev_alloc(T **p, size_t count) {
     return SSMAP_OK;
 }
 
+int dev_zero(void *p, size_t bytes) {
+    if (bytes == 0) return SSMAP_OK;
+    HIP_TRY(hipMemset(p, 0, bytes));
+    return SSMAP_OK;
+}
+
 }  // namespace
 
 struct ssmap_engine {
@@ -117,7 +123,7 @@ struct ssmap_engine {
     float *d_nb_probs = nullptr;           // [E][C][N] stage-1 probabilities when that rule is fed logits
     int palette_rows = 0;
     bool have_params = false, have_schema = false, have_palette = false;
-    Quat flip_cam{};
+    Quat flip_cam{}, flip_agent{};
     int device = 0;
     // egocentric observation maps (ssmap_set_egomap / ssmap_ego_maps)
     EgoTables *d_ego = nullptr;
@@ -207,8 +213,12 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     ssmap_engine *eng = new (std::nothrow) ssmap_engine();
     if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "out of host memory");
     eng->cfg = c;
-    HIP_TRY(hipGetDevice(&eng->device));
+    if (hipError_t err = hipGetDevice(&eng->device); err != hipSuccess) {
+        delete eng;
+        return fail(SSMAP_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(err));
+    }
     eng->flip_cam = qexp_half(M_PI, 0.0, 0.0);
+    eng->flip_agent = qexp_half(0.0, M_PI, 0.0);
     eng->envs.assign(c.n_envs, EnvState{});
     eng->h_hdr.assign(c.n_envs, FrameHeader{});
 
@@ -242,7 +252,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&v.wheight, EN));
     v.quad_stride = 4ll * c.max_map_h * c.max_map_w;
     TRY_ALLOC(dev_alloc(&v.quad, (size_t)v.E * v.quad_stride));
-    hipMemset(v.quad, 0, sizeof(int32_t) * v.E * v.quad_stride);
+    TRY_ALLOC(dev_zero(v.quad, sizeof(int32_t) * v.E * v.quad_stride));
     if (c.rule == SSMAP_RULE_GOAL_DECAY) {
         v.local_stride = 4ll * c.max_map_h * c.max_map_w;
         TRY_ALLOC(dev_alloc(&v.local_ids, (size_t)v.E * v.local_stride));
@@ -251,7 +261,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     for (int i = 0; i < 2; ++i) {
         if (c.rule == SSMAP_RULE_HV || c.rule == SSMAP_RULE_PROB_HV) TRY_ALLOC(dev_alloc(&v.overlay[i], EN));
         TRY_ALLOC(dev_alloc(&v.overlay_count[i], (size_t)v.E));
-        hipMemset(v.overlay_count[i], 0, sizeof(uint32_t) * v.E);
+        TRY_ALLOC(dev_zero(v.overlay_count[i], sizeof(uint32_t) * v.E));
     }
     TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
     TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
@@ -259,13 +269,13 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.path_cap = (int64_t)c.max_map_h * c.max_map_w;
     TRY_ALLOC(dev_alloc(&v.path_cells, (size_t)v.E * v.path_cap));
     TRY_ALLOC(dev_alloc(&v.path_count, (size_t)v.E));
-    hipMemset(v.path_count, 0, sizeof(uint32_t) * v.E);
+    TRY_ALLOC(dev_zero(v.path_count, sizeof(uint32_t) * v.E));
     eng->path_n.assign(c.n_envs, 0u);
     TRY_ALLOC(dev_alloc(&eng->d_nb, (size_t)6));
-    hipMemset(eng->d_nb, 0, 6 * sizeof(NbModel));
+    TRY_ALLOC(dev_zero(eng->d_nb, 6 * sizeof(NbModel)));
     v.nb = eng->d_nb;
-    hipMemset(eng->d_pool_count, 0, 6 * sizeof(int32_t));
-    hipMemset(eng->d_lut, 0, SSMAP_MAX_CLASSES * sizeof(int32_t));
+    TRY_ALLOC(dev_zero(eng->d_pool_count, 6 * sizeof(int32_t)));
+    TRY_ALLOC(dev_zero(eng->d_lut, SSMAP_MAX_CLASSES * sizeof(int32_t)));
 #undef TRY_ALLOC
     eng->h_poses.assign(c.n_envs, PoseBlock{});
     for (int i = 0; i < kPoseRing && c.n_envs > kPosePack; ++i) {
@@ -289,20 +299,38 @@ int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n, const int
     for (int i = 0; i < n; ++i)
         if (lut[i] < 0 || lut[i] >= eng->cfg.n_schema + 3) return fail(SSMAP_ERR_INVALID_ARG, "schema id out of range");
     HIP_TRY(hipMemcpy(eng->d_lut, lut, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    int32_t ids[6 * SSMAP_MAX_POOL] = {};
+    int32_t cnt[6] = {};
     if (pool_ids && pool_count) {
         for (int g = 0; g < 6; ++g) {
             if (pool_count[g] < 0 || pool_count[g] > SSMAP_MAX_POOL) return fail(SSMAP_ERR_INVALID_ARG, "pool too long");
             for (int k = 0; k < pool_count[g]; ++k)
                 if (pool_ids[g * SSMAP_MAX_POOL + k] < 0 || pool_ids[g * SSMAP_MAX_POOL + k] >= n)
                     return fail(SSMAP_ERR_INVALID_ARG, "pool class out of range");
+            cnt[g] = pool_count[g];
+            memcpy(ids + g * SSMAP_MAX_POOL, pool_ids + g * SSMAP_MAX_POOL, sizeof(int32_t) * pool_count[g]);
         }
-        HIP_TRY(hipMemcpy(eng->d_pool_ids, pool_ids, 6 * SSMAP_MAX_POOL * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(eng->d_pool_count, pool_count, 6 * sizeof(int32_t), hipMemcpyHostToDevice));
+    } else {
+        // no lists: every class the table maps to the goal id, ascending
+        for (int c = 0; c < n; ++c) {
+            const int g = lut[c] - 3;
+            if (g < 0 || g >= 6) continue;
+            if (cnt[g] >= SSMAP_MAX_POOL) return fail(SSMAP_ERR_INVALID_ARG, "more than 8 classes map to one goal id: pass pool lists");
+            ids[g * SSMAP_MAX_POOL + cnt[g]++] = c;
+        }
     }
+    HIP_TRY(hipMemcpy(eng->d_pool_ids, ids, sizeof(ids), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(eng->d_pool_count, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    // The pooled confidence of a pixel is its largest probability itself when every goal id is
+    // reached through exactly one class and that class is the goal's whole list.
     eng->view.pool_trivial = 1;
-    if (pool_ids && pool_count)
-        for (int g = 0; g < 6; ++g)
-            if (pool_count[g] > 1) eng->view.pool_trivial = 0;
+    for (int g = 0; g < 6; ++g) {
+        int mapped = 0, last = -1;
+        for (int c = 0; c < n; ++c)
+            if (lut[c] == g + 3) { ++mapped; last = c; }
+        if (mapped == 0) continue;   // no pixel can carry this id
+        if (mapped != 1 || cnt[g] != 1 || ids[g * SSMAP_MAX_POOL] != last) eng->view.pool_trivial = 0;
+    }
     eng->have_schema = true;
     return SSMAP_OK;
 }
@@ -562,9 +590,11 @@ int ssmap_ego_maps(ssmap_engine *eng, const double *agent_pose, const int32_t *g
         const double *ag = agent_pose + 7 * e;
         const ssmap_env_maps &mp = eng->envs[e].maps;
         EgoPose &p = eng->h_ego_poses[e];
-        // heading = R(agent rotation) (0,0,1); phi = atan2(heading z, heading x) (mapper.py:885-890)
+        // heading = R(agent rotation) (0,0,1); phi = atan2(heading z, heading x) (mapper.py:885-890),
+        // where the agent rotation is the pose quaternion times a half turn about y, as update_map
+        // passes it on (mapper.py:291-293, 840-847)
         double R[9];
-        qmatrix(Quat{ag[3], ag[4], ag[5], ag[6]}, R);
+        qmatrix(qmul(Quat{ag[3], ag[4], ag[5], ag[6]}, eng->flip_agent), R);
         const double phi = std::atan2(R[8], R[2]);
         // getRotationMatrix2D((side/2, side/2), deg(phi) + 90, 1) and warpAffine's inversion
         double angle = phi * (180.0 / M_PI) + 90;
@@ -636,7 +666,7 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         for (int e = 0; e < c.n_envs; ++e) {
             const int g = f->goal_sem_id[e];
             if (g < 3 || g > 8) return fail(SSMAP_ERR_INVALID_ARG, "goal id outside [3, 8]");
-            if (r == SSMAP_RULE_STUBBORN && !eng->nb_set[g - 3])
+            if (r == SSMAP_RULE_STUBBORN && !v.prm.nb_stats && !eng->nb_set[g - 3])
                 return fail(SSMAP_ERR_NOT_READY, "no naive-Bayes model for this goal (ssmap_set_nb_model)");
             const ssmap_env_maps &mp = eng->envs[e].maps;
             if (!mp.total_view || !mp.cumulative_conf || !mp.max_conf || !mp.max_other_conf)

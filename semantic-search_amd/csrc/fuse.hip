@@ -22,9 +22,10 @@ constexpr int kTile = 256;
 constexpr int kRegTile = 256;      // block of the register kernel (64 and 1024 threads measured slower)
 constexpr int kStride = kTile + 1;
 
-// scipy.special.entr: -x log x, 0 at 0, -inf below 0
+// scipy.special.entr: -x log x, 0 at 0, -inf below 0.  The full-precision logarithm: the kernel
+// that calls it waits on scattered memory, not on the vector unit.
 __device__ inline float entr(float x) {
-    if (x > 0.0f) return -x * __logf(x);
+    if (x > 0.0f) return -x * logf(x);
     return x == 0.0f ? 0.0f : (x != x ? x : -INFINITY);
 }
 
@@ -115,19 +116,26 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
         const int sid = v.lut[bi];
         float conf = inv_s;
         if (!a.pool_trivial && sid >= 3 && sid <= 8) {
-            // probability mass of every model class mapped to this goal id (infer.py:109-118)
-            float acc = 0.0f;
-            bool any = false;
+            // probability mass of the goal's listed model classes, added in list order like the
+            // reference's probs[ids].sum(axis=0) (infer.py:109-118, 318-327); an empty list gives 0.
+            // The list entries are wave-uniform, so a class is picked by a compare-and-select
+            // chain over the registers instead of a per-lane indexed read.
+            for (int g = 0; g < 6; ++g) {
+                if (!__ballot(sid == g + 3)) continue;
+                const int n = __builtin_amdgcn_readfirstlane(v.pool_count[g]);
+                float acc = 0.0f;
+                for (int k = 0; k < n; ++k) {
+                    const int idx = __builtin_amdgcn_readfirstlane(v.pool_ids[g * SSMAP_MAX_POOL + k]);
+                    float pv = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const bool hit = v.lut[c] == sid;
-                acc += hit ? x[c] : 0.0f;
-                any |= hit;
+                    for (int c = 0; c < CT; ++c) pv = c == idx ? x[c] : pv;
+                    acc = k == 0 ? pv : acc + pv;
+                }
+                conf = sid == g + 3 ? acc : conf;
             }
-            if (any) conf = acc;
         }
         if (active) {
-            const float unc = hsum * (-0.693147180559945309f / __logf((float)CT));
+            const float unc = hsum * (-0.693147180559945309f / logf((float)CT));
             if (a.sem_out) __builtin_nontemporal_store(sid, a.sem_out + fbase + pix);
             if (a.unc_out) __builtin_nontemporal_store(unc, a.unc_out + fbase + pix);
             if (a.maxp_out) __builtin_nontemporal_store(conf, a.maxp_out + fbase + pix);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
         }
         float s = 0.0f;
         for (int c = 0; c < C; ++c) {
-            const float ev = __expf(col[c * kStride] - m);
+            const float ev = expf(col[c * kStride] - m);
             col[c * kStride] = ev;
             s += ev;
         }
@@ -194,21 +202,24 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
         for (int c = 0; c < C; ++c) {
             const float p = col[c * kStride] * inv_s;
             col[c * kStride] = p;
-            hsum += p * __logf(p + 1e-6f);
+            hsum += p * logf(p + 1e-6f);
             if (p > best) { best = p; bi = c; }
         }
         const int sid = v.lut[bi];
         float conf = best;
-        if (sid >= 3 && sid <= 8) {
+        if (!a.pool_trivial && sid >= 3 && sid <= 8) {
             const int g = sid - 3;
             const int n = v.pool_count[g];
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += col[v.pool_ids[g * SSMAP_MAX_POOL + k] * kStride];
-            if (n > 0) conf = acc;
+            for (int k = 0; k < n; ++k) {
+                const float pv = col[v.pool_ids[g * SSMAP_MAX_POOL + k] * kStride];
+                acc = k == 0 ? pv : acc + pv;
+            }
+            conf = acc;   // an empty list sums to 0 (infer.py:116)
         }
         if (active) {
             if (a.sem_out) a.sem_out[fbase + pix] = sid;
-            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / __logf((float)C);
+            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / logf((float)C);
             if (a.maxp_out) a.maxp_out[fbase + pix] = conf;
             if (a.probs_out) {
                 float *dst = a.probs_out + ((int64_t)e * C) * v.N + pix;
@@ -236,6 +247,9 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
 // MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
 template <int MODE, int V, int K>
 __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__restrict__ gt) {
+    // every product and sum rounds on its own, as numpy's array statements do (mapper.py:540-548):
+    // with unit weights the fused average then equals the reference's bit for bit
+#pragma clang fp contract(off)
     typedef float VecF __attribute__((ext_vector_type(V)));
     constexpr int NB = V * K <= 4 ? 4 : 2;   // row-batches in flight per wave (of the 4 a pass needs)
     constexpr unsigned kRun = 64;     // list slots per block pass
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                         if (on && c < C) {
 #pragma unroll
                             for (int j = 0; j < V; ++j) {
-                                mv[b][k][j] = mv[b][k][j] + __logf(p[b][k][j] / p0);
+                                mv[b][k][j] = mv[b][k][j] + logf(p[b][k][j] / p0);
                                 { const bool take = arg_better(mv[b][k][j], c + j, best, bi); best = take ? mv[b][k][j] : best; bi = take ? c + j : bi; }
                             }
                             *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];

@@ -78,7 +78,8 @@ __device__ inline bool goal_statistics(const View &v, const ssmap_env_maps &mp, 
     mp.cumulative_conf[cell] = cum;
     mp.max_conf[cell] = mx;
     mp.max_other_conf[cell] = mo;
-    if (v.rule != SSMAP_RULE_STUBBORN) return true;
+    // while the training rows are being collected the model is not consulted (mapper.py:474-515)
+    if (v.rule != SSMAP_RULE_STUBBORN || v.prm.nb_stats) return true;
     const NbModel &m = v.nb[g];
     const double x[4] = {(double)views, (double)cum, (double)mx, (double)mo};
     double best = 0.0;

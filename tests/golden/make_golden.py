@@ -112,6 +112,10 @@ CASES = [
     dict(name="argmax_collect_nb", rule="height_map_argmax", prob=True, C=8, hw=(60, 80),
          frames=4, scene="room", start=(1.0, 1.0), step=0.5, yaw=YAW_IN,
          collect=True, goal_classes={3: [3]}),
+    # stubborn while the rows are collected: statistics kept, the models not consulted (mapper.py:474-515)
+    dict(name="stubborn_collect_nb", rule="height_map_stubborn", prob=True, C=8, hw=(48, 64),
+         frames=4, scene="room", start=(1.0, 1.0), step=0.5, yaw=YAW_IN, sharp=2.0,
+         nb=True, collect=True, goal_classes={3: [3]}),
     # the reference's 41- and 38-class schemas: goal ids 3, 11, 14, 18, 22, 10 (mapper.py:140-143),
     # no occupancy override, palette and path id sized by the schema
     dict(name="schema41_hv", rule="height_map_hv", prob=True, C=12, hw=(48, 64), n_schema=41, goal_index=2,

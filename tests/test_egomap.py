@@ -67,6 +67,43 @@ def test_warp_by_zero_angle_is_the_identity_and_quarter_turn_rotates():
     assert np.array_equal(out, np.rot90(img, 1))            # positive angle = counter-clockwise
 
 
+def test_heading_angle_equals_the_angle_the_reference_hands_to_opencv():
+    """tests/golden/ego/ego_pose.npz holds, for 16 agent poses, the angle and centre the reference's own
+    update_map -> ego_map passes to cv2.getRotationMatrix2D (mapper.py:291-293, 885-890, 922-923) and
+    the crop centre (mapper.py:891), recorded by tests/golden/make_ego_pose_golden.py."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ego", "ego_pose.npz"))
+    side = int(10.0 / 0.03) + 150
+    for pose, angle, centre, cell in zip(g["agent_pose"], g["angle_deg"], g["centre_xy"], g["agent_cell"]):
+        # numpy's vectorised arctan2 (what cartesian_to_polar calls) and libm's atan2 (the oracle, the
+        # engine) differ by a few units in the last place on some inputs
+        assert abs(np.rad2deg(eo.heading_angle(pose[3:])) + 90 - angle) <= 1e-12
+        assert tuple(centre) == (side / 2, side / 2)
+        d = pose[:3] - g["bounds"][:3]
+        assert np.array_equal(np.floor(np.array([d[2], d[0]]) / 0.03).astype(np.int64), cell)
+    # an agent with the identity rotation looks along -z after the half turn about y: phi = -pi/2,
+    # rotation angle 0, and the ego map is the unrotated crop around the agent
+    assert g["angle_deg"][0] == 0.0 and np.array_equal(g["agent_pose"][0][3:], [1.0, 0.0, 0.0, 0.0])
+
+
+def test_identity_rotation_gives_the_unrotated_crop():
+    rng = np.random.default_rng(5)
+    palette = mo.palette(12)
+    sem, color, unc = _random_maps(rng, 300, 280, palette, 3)
+    pos = np.array([4.0, 0.1, 4.5])
+    small, large, unc_s, unc_l = eo.ego_map(sem, color, unc, pos, np.array([1.0, 0.0, 0.0, 0.0]), np.zeros(3), 3,
+                                            palette, egomap_small_side_m=3.84, egomap_large_side_m=7.68)
+    # 7.68 m = 256 cells -> 2 x 2 box means of the crop centred on the agent's cell (150, 133)
+    r0, c0 = 150 - 128, 133 - 128
+    crop = color[r0:r0 + 256, c0:c0 + 256].astype(np.int64).copy()
+    crop[sem[r0:r0 + 256, c0:c0 + 256] == 3] = palette[9]
+    want = (crop.reshape(128, 2, 128, 2, 3).sum(axis=(1, 3)) + 2) >> 2
+    far = np.ones((128, 128), dtype=bool)
+    far[56:72, 56:72] = False                                  # away from the agent disk
+    assert np.array_equal(large[far], want[far].astype(np.uint8))
+    assert np.array_equal(unc_l[far], unc[r0:r0 + 256:2, c0:c0 + 256:2, 0][far])
+
+
 def test_crop_pads_with_zeros_outside_the_map():
     img = np.arange(25, dtype=np.uint32).reshape(5, 5) + 1
     out = eo.crop_fn(img, np.array([0, 4]), (4, 4))
@@ -75,6 +112,7 @@ def test_crop_pads_with_zeros_outside_the_map():
 
 
 def _random_maps(rng, rows, cols, palette, goal):
+    palette = np.asarray(palette)
     sem = rng.integers(0, 3, (rows, cols)).astype(np.uint32)
     for _ in range(25):
         r, c = rng.integers(0, rows), rng.integers(0, cols)

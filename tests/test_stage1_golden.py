@@ -49,7 +49,8 @@ def test_engine_stage1_matches_the_reference_tail(name):
     c, h, w = logits.shape
     eng = ssa.MapEngine(1, (h, w), depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
                         prob_aggregate="height_map_argmax", seg_model_n_classes=c, max_map_hw=(100, 100))
-    eng.set_schema(data["lut"])
+    # the goal classes in the order the reference's objnav2pred lists them (infer.py:77-79, 293-295)
+    eng.set_schema(data["lut"], s1.pooling_groups(data["lut"], meta["table_order"]))
     out = eng.stage1(torch.from_numpy(logits[None].copy()).cuda(), meta["temperature"], want_probs=True)
     torch.cuda.synchronize()
     probs = out["semantic_prob"][0].cpu().numpy().astype(np.float64)

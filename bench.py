@@ -2,6 +2,7 @@
 """Map-fusion throughput on MI355X: frames/s of the whole per-step fusion path.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          (starts N ranks itself, one per GPU, RCCL between them)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of stages 1-5 (softmax/entropy, back-projection, tallest-per-cell,
@@ -84,7 +85,7 @@ def algorithmic_bytes_per_frame(n_classes, k_updates, prob_rule):
     return geometry, stage1, state
 
 
-def cpu_baseline(workload, n_frames, seed):
+def cpu_baseline(workload, n_frames, seed, budget_s=25.0):
     """The CPU oracle (numpy port of the reference path) on the same workload, one core."""
     from oracle import mapper_oracle as mo
     from oracle import stage1_oracle as s1
@@ -117,7 +118,7 @@ def cpu_baseline(workload, n_frames, seed):
         if i > 0:   # first frame is warm-up
             elapsed += dt
             done += 1
-        if elapsed > 25.0:
+        if elapsed > budget_s:
             break
     return done / elapsed, done
 
@@ -137,6 +138,71 @@ def cpu_baseline_processes(workload, n_procs, n_frames):
     return sum(r[0] for r in res), sum(r[1] for r in res)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process (which never touches a GPU)
+    starts N ranks of itself, one per device like the reference's one worker per env shard
+    (eval_objnav.py:100, 144), and passes rank 0's line through."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, {have} visible: one rank per GPU over RCCL "
+              "needs that many devices", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
+
+
+def rehearse(args, rank, world):
+    """The multi-rank skeleton of main() without the engine: rendezvous, barrier, max and sum
+    reductions, one line from rank 0."""
+    import torch.distributed as dist
+    backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        sys.exit("bench.py --rehearse runs without GPUs: set SSMAP_BENCH_BACKEND=gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    metric = torch.tensor([float(args.steps * args.envs_per_gpu), 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(metric, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks": int(metric[1].item()),
+                          "frames": float(metric[0].item()), "slowest_rank_seconds": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernel_registers(name):
+    """VGPRs / waves per SIMD of a kernel from the committed compiler report."""
+    import csv
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_kernel_resources.csv")) as fh:
+            for row in csv.DictReader(fh):
+                if row["kernel"] == name:
+                    return {"vgpr": int(row["VGPRs"]), "sgpr": int(row["TotalSGPRs"]),
+                            "waves_per_simd": int(row["Occupancy [waves/SIMD]"]),
+                            "lds_bytes_per_block": int(row["LDS Size [bytes/block]"])}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,21 +212,35 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=60)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the block of --steps steps is repeated until this much time has been measured")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU work: ranks only meet, reduce a dummy metric and rank 0 prints a stub line "
+                         "(a CPU check of the launch path; needs SSMAP_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if args.rehearse:
+        return rehearse(args, rank, world)
     cpu_many = None
     if world == 1 and not args.no_cpu_baseline:
         # forked workers: before anything here initialises the GPU
         n_procs = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
-        cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 10)
+        cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 8)
     dist = None
     # RCCL between the ranks of a node; SSMAP_BENCH_BACKEND=gloo lets several ranks share one GPU
     # (a rehearsal of the multi-rank path on a one-GPU box: RCCL refuses two ranks on one device)
     backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
-    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        sys.exit(f"bench.py: {world} ranks but {n_dev} GPUs visible")
+    device = torch.device("cuda", local_rank % max(n_dev, 1))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -192,46 +272,58 @@ def main():
     maxp = torch.empty((E, H, W), dtype=torch.float32, device=device)
     goals = np.full(E, 3, dtype=np.int32)
     prng = np.random.default_rng(1000 + rank)
-    total_steps = args.warmup + 2 * args.steps
-    poses = [make_poses(E, span / 2, prng) for _ in range(total_steps)]
+    poses = [make_poses(E, span / 2, prng) for _ in range(256)]   # a new random yaw every step
+    counter = [0]
 
-    def one_step(i):
-        ag, cam = poses[i]
+    def one_step():
+        ag, cam = poses[counter[0] % len(poses)]
+        counter[0] += 1
         eng.step(depth, ag, cam, goals, logits=logits, temperature=wl["T"], semantic=sem,
                  semantic_unc=unc, semantic_max_prob=maxp, semantic_gt=gt)
+
+    red_dev = device if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_block():
+        """Exactly --steps steps between two barriers; the slowest rank's time."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for _ in range(args.warmup):
+        one_step()
+    blocks = [timed_block()]
+    # the same block again until min-seconds have been measured (every rank sees the same
+    # reduced times, so every rank runs the same number of blocks)
+    while sum(blocks) < args.min_seconds and len(blocks) < 200:
+        blocks.append(timed_block())
+    elapsed = float(np.median(blocks))
     found, status, n_upd = eng.results()
     assert not status.any(), "engine reported an index error on a benchmark frame"
 
-    # second pass of the same K steps with per-stage HIP events on the launch stream
+    # one more pass of the same K steps with per-stage HIP events on the launch stream
     eng.profile_begin(args.steps)
-    for i in range(args.steps):
-        one_step(args.warmup + args.steps + i)
+    for _ in range(args.steps):
+        one_step()
     stage_ms, n_prof = eng.profile_read()
     found, status, n_upd = eng.results()
 
-    red_dev = device if backend == "nccl" else torch.device("cpu")
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    metric = torch.tensor([float(args.steps * E), float(found.sum()), float(n_upd.sum())],
+    metric = torch.tensor([float(args.steps * E), float(found.sum()), float(n_upd.sum()), 1.0],
                           dtype=torch.float64, device=red_dev)
     if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(metric, op=dist.ReduceOp.SUM)   # the path's only exchange: final metric sum
-    elapsed = float(t_max.item())
     frames_total = float(metric[0].item())
+    ranks_seen = int(metric[3].item())
 
     if rank == 0:
         k_mean = float(n_upd.mean())
@@ -247,6 +339,8 @@ def main():
                 traffic = json.load(fh).get(args.workload, {}).get(f"E{E}", {}).get("k_stream_bytes_per_launch")
         except OSError:
             pass
+        mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
+        dom_name = f"k_stream_reg<{C}, {mode}>"
         names = ("geometry", "winners", "stream_stage1", "rule_update", "found")
         line = {
             "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",
@@ -264,24 +358,37 @@ def main():
             "config": {"workload": f"{wl['rule']}, {E} envs per GPU, 640x480 frames, {C} classes, "
                                    f"logits in (T={wl['T']}), {map_hw[0]}x{map_hw[1]} map",
                        "envs_per_gpu": E, "frames_per_step": E * world,
+                       "ranks": ranks_seen, "backend": backend if world > 1 else None,
                        "mean_update_cells_per_frame": k_mean,
                        "algorithmic_MB_per_frame": (geo_b + s1_b + state_b) / 1e6,
                        "whole_path_frac_of_hbm_peak":
                            (geo_b + s1_b + state_b) * (frames_total / world / elapsed) / 1e9 / HBM_PEAK_GBS},
-            "roofline": {"bound": "hbm", "kernel": "k_stream_reg (stage 1 fused softmax/entropy pass)",
+            "timing": {"blocks_of_steps": len(blocks), "seconds_measured": float(sum(blocks)),
+                       "ms_per_step_median": 1e3 * elapsed / args.steps,
+                       "ms_per_step_min": 1e3 * min(blocks) / args.steps,
+                       "ms_per_step_max": 1e3 * max(blocks) / args.steps,
+                       "value_from": "median block, slowest rank"},
+            "roofline": {"bound": "hbm", "kernel": dom_name + " (stage 1 fused softmax/entropy pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms},
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                         "registers": kernel_registers(dom_name)},
             "stage_ms_per_step": {nm: stage_ms[k] / max(n_prof, 1) for k, nm in enumerate(names)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0)
+            fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0, budget_s=12.0)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": f"{n_done} frames of the same workload (1 env, stage 1 on "
                                               "torch CPU + numpy oracle), 1 thread",
                                     "all_cores": {"value": cpu_many[1], "unit": "frames/s", "cores": cpu_many[0],
                                                   "sample": f"{cpu_many[2]} frames over {cpu_many[0]} independent "
                                                             "processes, one env each, run at the same time"}}
+            if args.workload != "avg_prob_c40":
+                # BASELINE configs[0]: height_map_avg_prob, one env, the reference's CPU-runnable case
+                fps0, n0 = cpu_baseline("avg_prob_c40", args.cpu_frames, seed=0, budget_s=12.0)
+                line["cpu_baseline"]["config0_avg_prob_1env"] = {
+                    "value": fps0, "unit": "frames/s", "cores": 1, "kind": "port",
+                    "sample": f"{n0} frames of height_map_avg_prob, 1 env, 640x480x40, 480x480 map, 1 thread"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

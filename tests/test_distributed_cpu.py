@@ -54,3 +54,37 @@ def test_two_rank_reduce_equals_single_process(tmp_path):
         for k in sharding.METRIC_FIELDS[1:]:
             assert abs(got["res"][k] - want[k]) < 1e-12
         assert np.allclose(got["res"]["per_goal_success"], want["per_goal_success"], equal_nan=True)
+
+
+def _bench(*argv, **env):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    full.update(env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=full,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks, they meet over
+    gloo, reduce, and rank 0 prints one line that says two ranks took part."""
+    import json
+    res = _bench("--gpus", "2", "--rehearse", "--steps", "5", "--envs-per-gpu", "3", SSMAP_BENCH_BACKEND="gloo")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["frames"] == 2 * 5 * 3
+    assert out["slowest_rank_seconds"] == 2.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """RCCL needs one device per rank: asking for more GPUs than are visible fails loudly instead
+    of printing a one-GPU number."""
+    import torch
+    n = torch.cuda.device_count()
+    res = _bench("--gpus", str(n + 2), "--no-cpu-baseline")
+    assert res.returncode != 0
+    assert "visible" in res.stderr and not any(ln.startswith("{") for ln in res.stdout.splitlines())

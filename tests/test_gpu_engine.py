@@ -121,7 +121,7 @@ def test_stage1_goal_confidence_follows_the_pool_lists(n_classes):
     kernel, 40 and 150 the register kernels; both must give the same bits as each other's sums, so
     the comparison with the oracle is at 1e-6 relative."""
     import semantic_search_amd as ssa
-    h, w = 40, 64
+    h, w = 96, 128
     rng = np.random.default_rng(100 + n_classes)
     logits = (1.5 * rng.standard_normal((1, n_classes, h, w))).astype(np.float32)
     lut = np.full(n_classes, 2, dtype=np.int64)

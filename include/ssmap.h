@@ -171,6 +171,23 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps);
  * (mapper.py:276-821): stages 1-5 enqueued on `stream` (a hipStream_t passed as void*). */
 int ssmap_step(ssmap_engine *eng, const ssmap_frames *frames, void *stream);
 
+/* ssmap_step for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments, same kernels and bit-identical results; the difference is where the per-step
+ * scratch lives (pixel records, per-block counts, owner flags, update list, staged probability
+ * rows, goal_decay's local maps): not in the block ssmap_create allocated but in a file-scope
+ * device array of SSMAP_STATIC_SCRATCH_BYTES that every GPU loading the library holds until the
+ * process ends.  The call allocates and frees nothing.  It returns SSMAP_ERR_UNSUPPORTED, with
+ * the two sizes in ssmap_last_error(), when the engine's per-step scratch is larger than the
+ * array (it grows with n_envs * img_h * img_w and, for the probability rules, n_classes), and
+ * when the stubborn rule / collect_nb_data is fed logits before any ssmap_step allocated its
+ * probability buffer.  All engines on one GPU share the array: nothing in it is carried from one
+ * step to the next (every step rewrites what it reads), but calls that overlap in time on one
+ * GPU (two streams, two threads) race; ssmap_update_list after such a step points into the array
+ * and is valid until the next ssmap_step_noalloc on that GPU. */
+#define SSMAP_STATIC_SCRATCH_BYTES (64u << 20)
+int ssmap_step_noalloc(ssmap_engine *eng, const ssmap_frames *frames, void *stream);
+
 /* Stage 1 alone: the softmax/entropy/confidence tail of predict()
  * (infer.py:97-118, 302-327).  probs_out may be NULL. */
 int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature,

@@ -10,13 +10,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libssmap.so")
 
 MAX_CLASSES = 256
 MAX_POOL = 8
+STATIC_SCRATCH_BYTES = 64 << 20
 
 RULES = {"direct": 0, "argmax": 1, "goal_decay": 2, "avg_prob": 3, "w_avg_prob": 4,
          "w2_avg_prob": 5, "log_odds": 6, "hv": 7, "prob_hv": 8, "stubborn": 9}
 ENV_INDEX_ERROR = 1
 
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
-           "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_stage1",
+           "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_step_noalloc", "ssmap_stage1",
            "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
            "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_set_nb_model", "ssmap_path_append", "ssmap_path_paint", "ssmap_last_error", "ssmap_version")
 
@@ -88,6 +89,7 @@ def load():
     lib.ssmap_set_params.argtypes = [vp, C.POINTER(Params)]
     lib.ssmap_bind_env.argtypes = [vp, i32, C.POINTER(EnvMaps)]
     lib.ssmap_step.argtypes = [vp, C.POINTER(Frames), vp]
+    lib.ssmap_step_noalloc.argtypes = [vp, C.POINTER(Frames), vp]
     lib.ssmap_stage1.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.ssmap_read_results.argtypes = [vp, vp, vp, vp, vp]
     lib.ssmap_update_list.argtypes = [vp, i32, C.POINTER(vp)]

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ssmap_internal.h"
@@ -101,6 +102,47 @@ int dev_zero(void *p, size_t bytes) {
     return SSMAP_OK;
 }
 
+// Per-step scratch: everything a step writes and reads again within the same step (pixel records,
+// per-block counts and reports, owner flags, update list, staged probability rows, goal_decay's
+// local maps).  One layout for both homes of it: the block ssmap_create allocates, and the
+// file-scope array below that ssmap_step_noalloc uses instead.  Returns the bytes needed; with
+// `base` the pointers of `v` are set.
+size_t carve_step_scratch(const ssmap_config &c, View &v, unsigned char *base) {
+    size_t at = 0;
+    auto take = [&](auto *&ptr, size_t count) {
+        using T = std::remove_reference_t<decltype(*ptr)>;
+        at = (at + 255) & ~size_t(255);
+        if (base) ptr = count ? reinterpret_cast<T *>(base + at) : nullptr;
+        at += count * sizeof(T);
+    };
+    const bool prob_rule = c.rule >= SSMAP_RULE_AVG_PROB && c.rule <= SSMAP_RULE_LOG_ODDS;
+    const size_t E = (size_t)c.n_envs, N = (size_t)c.img_h * c.img_w, EN = E * N;
+    const size_t geom_blocks = (N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
+    const size_t n_rec = E * kMaxParts * geom_blocks * kGeomPixPerBlock;
+    const bool packed = N <= (size_t(1) << kPackPixBits);
+    take(v.geo_part, E * geom_blocks);
+    take(v.bin_cnt, E * kMaxParts * geom_blocks);
+    take(v.rec_h, n_rec);
+    take(v.rec_w, n_rec);
+    take(v.rec_s, packed ? 0 : n_rec);
+    take(v.target, prob_rule ? EN : 0);
+    take(v.wflag, prob_rule ? EN : 0);
+    take(v.wprob, prob_rule ? EN * (size_t)c.n_classes : 0);
+    take(v.winners, EN * 2);
+    take(v.wheight, EN);
+    const size_t local = c.rule == SSMAP_RULE_GOAL_DECAY ? E * 4 * (size_t)c.max_map_h * c.max_map_w : 0;
+    take(v.local_ids, local);
+    take(v.local_eroded, local);
+    return (at + 255) & ~size_t(255);
+}
+
+// Home of the per-step scratch for ssmap_step_noalloc: a file-scope device array, one copy per
+// GPU that loads this library, held until the process ends.  In host code the name is only a
+// handle for hipGetSymbolAddress; the device address it returns (per device) is what kernels and
+// copies get.
+constexpr size_t kStaticScratchBytes = SSMAP_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 }  // namespace
 
 struct ssmap_engine {
@@ -125,6 +167,10 @@ struct ssmap_engine {
     bool have_params = false, have_schema = false, have_palette = false;
     Quat flip_cam{}, flip_agent{};
     int device = 0;
+    unsigned char *d_step = nullptr;       // per-step scratch of ssmap_step (carve_step_scratch)
+    unsigned char *d_static = nullptr;     // this device's copy of the file-scope array, for ssmap_step_noalloc
+    size_t step_bytes = 0;
+    const int32_t *last_list = nullptr;    // update list of the last step (either home)
     // egocentric observation maps (ssmap_set_egomap / ssmap_ego_maps)
     EgoTables *d_ego = nullptr;
     std::vector<EgoTables> h_ego;          // one element once configured
@@ -169,8 +215,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     if (!eng) return;
     View &v = eng->view;
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
-    hipFree(v.geo_part); hipFree(v.bin_cnt); hipFree(v.rec_h); hipFree(v.rec_w); hipFree(v.rec_s); hipFree(v.target); hipFree(v.wflag); hipFree(v.wprob); hipFree(v.winners); hipFree(v.wheight); hipFree(v.quad);
-    hipFree(v.local_ids); hipFree(v.local_eroded);
+    hipFree(eng->d_step); hipFree(v.quad);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
     hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
     hipFree(eng->d_disk); hipFree(eng->d_palette); hipFree(eng->d_ego);
@@ -236,28 +281,24 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
     v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
-    const size_t n_rec = (size_t)v.E * kMaxParts * v.geom_blocks * kGeomPixPerBlock;
-    TRY_ALLOC(dev_alloc(&v.geo_part, (size_t)v.E * v.geom_blocks));
-    TRY_ALLOC(dev_alloc(&v.bin_cnt, (size_t)v.E * kMaxParts * v.geom_blocks));
-    TRY_ALLOC(dev_alloc(&v.rec_h, n_rec));
-    TRY_ALLOC(dev_alloc(&v.rec_w, n_rec));
-    if (!v.rec_packed) TRY_ALLOC(dev_alloc(&v.rec_s, n_rec));
-    if (prob_rule) {
-        TRY_ALLOC(dev_alloc(&v.target, EN));
-        TRY_ALLOC(dev_alloc(&v.wflag, EN));
-        v.wprob_stride = v.C;   // padding the rows to whole cache lines measured slower
-        TRY_ALLOC(dev_alloc(&v.wprob, EN * (size_t)v.wprob_stride));
+    v.wprob_stride = v.C;   // padding the rows to whole cache lines measured slower
+    v.local_stride = 4ll * c.max_map_h * c.max_map_w;
+    eng->step_bytes = carve_step_scratch(c, v, nullptr);
+    TRY_ALLOC(dev_alloc(&eng->d_step, eng->step_bytes));
+    carve_step_scratch(c, v, eng->d_step);
+    // this device's address of the file-scope scratch array (ssmap_step_noalloc)
+    {
+        void *sym = nullptr;
+        hipError_t err = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || !sym) {
+            ssmap_destroy(eng);
+            return fail(SSMAP_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(err));
+        }
+        eng->d_static = static_cast<unsigned char *>(sym);
     }
-    TRY_ALLOC(dev_alloc(&v.winners, EN * 2));
-    TRY_ALLOC(dev_alloc(&v.wheight, EN));
     v.quad_stride = 4ll * c.max_map_h * c.max_map_w;
     TRY_ALLOC(dev_alloc(&v.quad, (size_t)v.E * v.quad_stride));
     TRY_ALLOC(dev_zero(v.quad, sizeof(int32_t) * v.E * v.quad_stride));
-    if (c.rule == SSMAP_RULE_GOAL_DECAY) {
-        v.local_stride = 4ll * c.max_map_h * c.max_map_w;
-        TRY_ALLOC(dev_alloc(&v.local_ids, (size_t)v.E * v.local_stride));
-        TRY_ALLOC(dev_alloc(&v.local_eroded, (size_t)v.E * v.local_stride));
-    }
     for (int i = 0; i < 2; ++i) {
         if (c.rule == SSMAP_RULE_HV || c.rule == SSMAP_RULE_PROB_HV) TRY_ALLOC(dev_alloc(&v.overlay[i], EN));
         TRY_ALLOC(dev_alloc(&v.overlay_count[i], (size_t)v.E));
@@ -632,7 +673,9 @@ static int check_ready(ssmap_engine *eng) {
     return SSMAP_OK;
 }
 
-int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
+// One step; `static_home` says where the per-step scratch lives: the engine's own block
+// (ssmap_step) or this device's copy of the file-scope array (ssmap_step_noalloc).
+static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, bool static_home) {
     if (!eng || !f) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
     int rc = check_ready(eng);
     if (rc != SSMAP_OK) return rc;
@@ -676,6 +719,9 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
             v.nb_probs = f->probs;
         } else {
             if (!eng->d_nb_probs) {   // first step fed with logits: room for one batch of probabilities
+                if (static_home)
+                    return fail(SSMAP_ERR_UNSUPPORTED, "ssmap_step_noalloc: goal statistics fed by logits need a "
+                                "probability buffer that an earlier ssmap_step would have allocated; pass semantic_prob");
                 rc = dev_alloc(&eng->d_nb_probs, (size_t)v.E * v.C * v.N);
                 if (rc != SSMAP_OK) return rc;
             }
@@ -712,32 +758,50 @@ int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
         HIP_TRY(hipEventRecord(eng->pose_done[slot], stream));
     }
 
+    // the view the kernels get: the engine's, with the per-step scratch at its home for this call
+    View lv = v;
+    if (static_home) {
+        if (eng->step_bytes > kStaticScratchBytes)
+            return fail(SSMAP_ERR_UNSUPPORTED, "ssmap_step_noalloc: this engine's per-step scratch (" +
+                        std::to_string(eng->step_bytes) + " bytes) exceeds the static array (" +
+                        std::to_string(kStaticScratchBytes) + " bytes); use ssmap_step");
+        carve_step_scratch(c, lv, eng->d_static);
+    }
+    eng->last_list = lv.winners;
     hipEvent_t *marks = nullptr;
     if (eng->prof_capacity && eng->prof_steps < eng->prof_capacity)
         marks = eng->prof_events.data() + (size_t)kProfMarks * eng->prof_steps++;
 #define MARK(i) do { if (marks) HIP_TRY(hipEventRecord(marks[i], stream)); } while (0)
     MARK(0);
-    launch_geometry(v, *f, packed ? pb : nullptr, stream);
+    launch_geometry(lv, *f, packed ? pb : nullptr, stream);
     MARK(1);
-    launch_winners(v, *f, stream);
-    launch_resolve_wrapped(v, stream);
+    launch_winners(lv, *f, stream);
+    launch_resolve_wrapped(lv, stream);
     MARK(2);
     if (prob_rule) {
-        launch_stream(v, *f, true, nullptr, stream);
+        launch_stream(lv, *f, true, nullptr, stream);
         MARK(3);
-        launch_update_prob(v, *f, stream);
+        launch_update_prob(lv, *f, stream);
     } else {
-        if (f->logits) launch_stream(v, *f, false, goal_stats ? eng->d_nb_probs : nullptr, stream);
+        if (f->logits) launch_stream(lv, *f, false, goal_stats ? eng->d_nb_probs : nullptr, stream);
         MARK(3);
-        launch_label_rules(v, *f, stream);
+        launch_label_rules(lv, *f, stream);
     }
     MARK(4);
-    launch_found(v, stream);
+    launch_found(lv, stream);
     MARK(5);
 #undef MARK
     HIP_TRY(hipGetLastError());
     v.cur_overlay ^= 1;
     return SSMAP_OK;
+}
+
+int ssmap_step(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
+    return step_impl(eng, f, stream_v, false);
+}
+
+int ssmap_step_noalloc(ssmap_engine *eng, const ssmap_frames *f, void *stream_v) {
+    return step_impl(eng, f, stream_v, true);
 }
 
 int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature, int32_t *semantic,
@@ -803,7 +867,7 @@ int ssmap_profile_read(ssmap_engine *eng, double *stage_ms, int32_t *n_steps, vo
 
 int ssmap_update_list(ssmap_engine *eng, int32_t e, const int32_t **pairs_dev) {
     if (!eng || !pairs_dev || e < 0 || e >= eng->cfg.n_envs) return fail(SSMAP_ERR_INVALID_ARG, "bad env index");
-    *pairs_dev = eng->view.winners + 2ll * e * eng->view.N;
+    *pairs_dev = (eng->last_list ? eng->last_list : eng->view.winners) + 2ll * e * eng->view.N;
     return SSMAP_OK;
 }
 

@@ -332,8 +332,10 @@ class MapEngine:
              temperature: float = 1.0, semantic: Optional[torch.Tensor] = None,
              semantic_unc: Optional[torch.Tensor] = None,
              semantic_max_prob: Optional[torch.Tensor] = None,
-             semantic_gt: Optional[torch.Tensor] = None):
-        """Enqueues stages 1-5 for all envs on the current stream.  Tensors are [E, ...] on the
+             semantic_gt: Optional[torch.Tensor] = None, static_scratch: bool = False):
+        """Enqueues stages 1-5 for all envs on the current stream.  With `static_scratch` the
+        allocation-free entry point runs the step (per-step scratch in the library's file-scope
+        device array; raises when this engine's scratch does not fit).  Tensors are [E, ...] on the
         engine's device, contiguous; `depth` is modified in place (sentinels zeroed).  Poses are
         host arrays [E,7] float64; goal_sem_ids host ints [E]."""
         E, H, W = self.n_envs, self.img_h, self.img_w
@@ -365,7 +367,8 @@ class MapEngine:
                 _capi.check(self.lib.ssmap_set_params(self._h, C.byref(pk)))
                 object.__setattr__(self.params, "dirty", False)
             stream = torch.cuda.current_stream().cuda_stream
-            _capi.check(self.lib.ssmap_step(self._h, C.byref(fr), C.c_void_p(stream)))
+            entry = self.lib.ssmap_step_noalloc if static_scratch else self.lib.ssmap_step
+            _capi.check(entry(self._h, C.byref(fr), C.c_void_p(stream)))
 
     def stage1(self, logits: torch.Tensor, temperature: float, want_probs: bool = False):
         """The softmax / entropy / confidence tail of predict() for [E,C,H,W] logits."""

@@ -273,6 +273,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.depth_min = c.depth_min; v.depth_max = c.depth_max;
     v.fx = c.fx; v.fy = c.fy; v.p2m = c.pixel2meter;
     v.inv_fx = 1.0 / c.fx; v.inv_fy = 1.0 / c.fy; v.inv_p2m = 1.0 / c.pixel2meter;
+    v.inv_fx_wide = v.inv_fx * (1.0 + 0x1p-20); v.inv_fy_wide = v.inv_fy * (1.0 + 0x1p-20);
     const size_t EN = (size_t)v.E * v.N;
     int rc = SSMAP_OK;
 #define TRY_ALLOC(call) do { rc = (call); if (rc != SSMAP_OK) { ssmap_destroy(eng); return rc; } } while (0)

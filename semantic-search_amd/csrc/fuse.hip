@@ -21,6 +21,7 @@ namespace ssmap {
 constexpr int kTile = 256;
 constexpr int kRegTile = 256;      // block of the register kernel (64 and 1024 threads measured slower)
 constexpr int kStride = kTile + 1;
+constexpr int kStageRows = 8;      // owner rows a wave of the register kernel stages per pass
 
 // scipy.special.entr: -x log x, 0 at 0, -inf below 0.  The full-precision logarithm: the kernel
 // that calls it waits on scattered memory, not on the vector unit.
@@ -148,17 +149,60 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     }
     if (MODE == 0) return;
 
-    // an owner writes its own row: CT / 4 vector stores under the owners' execution mask
-    if (slot >= 0) {
-        float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
-        if (CT % 4 == 0) {
+    // The owners' rows leave the wave through LDS: the few owner lanes (3 to 4 of 64 on a typical
+    // frame) park their C probabilities in the wave's staging rows, then consecutive lanes write
+    // consecutive vectors of those rows, so that a wave issues one or two store instructions
+    // instead of C / 4 under a sparse execution mask (a vector store occupies the memory pipeline
+    // for its full width whatever the mask).  Wave-local: no block barrier, the LDS accesses of one
+    // wave are executed in order.
+    constexpr int V = CT % 4 == 0 ? 4 : (CT % 2 == 0 ? 2 : 1);
+    constexpr int U = CT / V;
+    typedef float VecT __attribute__((ext_vector_type(V)));
+    constexpr int kLdsRows = (CT % 4 == 0 && CT <= 64) ? kStageRows : 1;
+    __shared__ __attribute__((aligned(16))) float s_rows[kRegTile / 64][kLdsRows][CT];
+    __shared__ int s_slot[kRegTile / 64][kLdsRows];
+    if (!(CT % 4 == 0 && CT <= 64)) {
+        // wide rows: the staging rows would cost more than they save (150 classes measured 6 %
+        // slower through LDS); the owner writes its own row with the widest aligned vector
+        if (slot >= 0) {
+            float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
 #pragma unroll
-            for (int q = 0; q < CT / 4; ++q)
-                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-        } else {
+            for (int q = 0; q < U; ++q) {
+                VecT val;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) dst[c] = x[c];
+                for (int j = 0; j < V; ++j) val[j] = x[V * q + j];
+                *reinterpret_cast<VecT *>(dst + V * q) = val;
+            }
         }
+        return;
+    }
+    const unsigned long long owners = __ballot(slot >= 0);
+    if (owners == 0ull) return;
+    const int wave = t >> 6, lane = t & 63;
+    const int n_own = __popcll(owners);
+    const int rank = __popcll(owners & ((1ull << lane) - 1ull));
+    for (int r0 = 0; r0 < n_own; r0 += kStageRows) {
+        if (slot >= 0 && rank >= r0 && rank < r0 + kStageRows) {
+            float *row = s_rows[wave][rank - r0];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                VecT val;
+#pragma unroll
+                for (int j = 0; j < V; ++j) val[j] = x[V * q + j];
+                *reinterpret_cast<VecT *>(row + V * q) = val;
+            }
+            s_slot[wave][rank - r0] = slot;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int rows = min(kStageRows, n_own - r0);
+        for (int j = lane; j < rows * U; j += 64) {
+            const int k = j / U, q = j - k * U;
+            const VecT val = *reinterpret_cast<const VecT *>(&s_rows[wave][k][V * q]);
+            *reinterpret_cast<VecT *>(v.wprob + (fbase + s_slot[wave][k]) * v.wprob_stride + V * q) = val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

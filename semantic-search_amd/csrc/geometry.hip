@@ -51,26 +51,20 @@ __device__ inline unsigned wave_minu(unsigned x) {
     return x;
 }
 
-// Correctly rounded a / b for a divisor known in advance (rb = RN(1/b) from the host).  Two
-// fused steps give a candidate q; the exact residual r = a - b*q then PROVES that q is the
-// nearest double (|r| strictly below half an ulp of q times |b|, q not a power of two), in
-// which case q equals the IEEE quotient.  `sure` is cleared when the proof fails; the caller
-// then redoes the whole pixel with hardware divisions (one rare branch per pixel instead of one
-// per division).
-__device__ inline double div_known(double a, double b, double rb, bool &sure) {
+// Correctly rounded a / b for a positive divisor known in advance (rb = RN(1/b) from the host,
+// rb_wide = rb (1 + 2^-20)).  Two fused steps give a candidate q, the residual r = a - b q says
+// how far it is from the quotient: a / b = q + r / b.  r is exact whenever q is one of the two
+// doubles around a / b; then RN(q + r rb_wide) == q PROVES |r / b| < the distance from q to the
+// edge of its rounding interval (r rb_wide exceeds r / b in magnitude: b rb >= 1 - 2^-53), i.e.
+// q = RN(a / b).  A q further off has |r / b| of an ulp or more and fails the test.  `sure` is
+// cleared when the proof fails; the caller then redoes the whole pixel with hardware divisions
+// (one rare branch per pixel instead of one per division).  a = +0 gives +0 like a / b.
+__device__ inline double div_known(double a, double b, double rb, double rb_wide, bool &sure) {
     const double q0 = a * rb;
     const double q = __builtin_fma(__builtin_fma(-b, q0, a), rb, q0);
     const double r = __builtin_fma(-b, q, a);
-    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(long long, q);
-    const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-    // q must be a normal number away from both ends of the exponent range (half_ulp below is built
-    // from its exponent) and not a power of two (the spacing below a power of two is halved)
-    const bool plain = ex > 60u && ex < 0x7FEu && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
-    const double half_ulp = __builtin_bit_cast(double, (long long)((unsigned long long)(ex - 53u) << 52));
-    // a == 0 gives the signed zero a / b gives
-    // half_ulp is a power of two, so the product on the right is exact and so is the comparison
-    sure &= (a == 0.0) | (plain & (fabs(r) < half_ulp * fabs(b)));
-    return a == 0.0 ? q0 : q;
+    sure &= __builtin_fma(r, rb_wide, q) == q;
+    return q;
 }
 
 // floor(RN(d / p)) for a divisor known in advance: d * RN(1/p) is within 3.4e-16 relative of
@@ -115,8 +109,8 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
     if (ok) {
         z = (double)dk;
         const double ax = z * ((double)u - (double)v.W / 2.0), ay = z * yr;
-        x = FAST ? div_known(ax, v.fx, v.inv_fx, sure) : ax / v.fx;
-        y = FAST ? div_known(ay, v.fy, v.inv_fy, sure) : ay / v.fy;
+        x = FAST ? div_known(ax, v.fx, v.inv_fx, v.inv_fx_wide, sure) : ax / v.fx;
+        y = FAST ? div_known(ay, v.fy, v.inv_fy, v.inv_fy_wide, sure) : ay / v.fy;
     }
     const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
     const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
@@ -127,6 +121,15 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
     g.key = 0;
     g.row = g.col = 0;
     g.invalid = !ok;
+    const bool pass = ok && (wy < pb.h_cut);
+    if (FAST) {
+        // a proven pixel has |coordinate / cell| < 2^24 and finite: integer comparisons
+        const int row = (int)fr, col = (int)fc;
+        const bool below_upper = row < Hm && col < Wm;
+        const bool above_lower = row >= -Hm && col >= -Wm;
+        g.in_box = below_upper && above_lower;
+        g.index_error = below_upper && !above_lower && pass;
+    } else {
     // Comparisons in double so that huge or non-finite coordinates never reach a cast.  numpy
     // casts the floored coordinate to int64 (mapper.py:863), and the x86 conversion turns a NaN,
     // an infinity and any value beyond the int64 range into INT64_MIN: such a coordinate passes
@@ -134,9 +137,9 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
     const bool r_min = !(fr < 9223372036854775808.0), c_min = !(fc < 9223372036854775808.0);
     const bool below_upper = (r_min || fr < (double)Hm) && (c_min || fc < (double)Wm);
     const bool above_lower = !r_min && !c_min && fr >= -(double)Hm && fc >= -(double)Wm;
-    const bool pass = ok && (wy < pb.h_cut);
     g.in_box = below_upper && above_lower && wy == wy;
     g.index_error = !g.in_box && below_upper && !above_lower && pass;   // index below -dim: numpy raises IndexError
+    }
     if (g.in_box) {
         g.row = (int)fr;
         g.col = (int)fc;
@@ -251,8 +254,14 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
     __shared__ unsigned int s_cnt[kBinParts];
     __shared__ unsigned int s_inv, s_err, s_spill;
     __shared__ int s_box[4];
+    __shared__ unsigned long long s_h[kBinParts][64];
+    __shared__ uint32_t s_w[kBinParts][64];
+    __shared__ uint32_t s_s[PACKED ? 1 : kBinParts][64];
     const int e = blockIdx.y;
     const int64_t fbase = (int64_t)e * v.N;
+    const int64_t blk_base = rec_table_base(v, e, 0) + ((int64_t)blockIdx.x << 6);
+    const uint32_t part_stride = (uint32_t)v.geom_blocks * 64u;
+    const uint32_t row_stride = (uint32_t)v.E * kBinParts * part_stride;
     const PoseBlock &pb = POSE_ARG ? pack.p[blockIdx.y] : v.poses[e];
     const ssmap_env_maps &mp = v.envs[e].maps;
     if (blockIdx.x == 0) {
@@ -349,26 +358,30 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             place4[k] = part_slot[k] != kDeadCell ? atomicAdd(&s_cnt[part_slot[k] >> 16], 1u) : 0u;
+        // Row 0 of every share (its first 64 places, which hold nearly all records) is staged in LDS
+        // and written out after the barrier below, one table row per store instruction: a lane
+        // writing its own record is one memory request per record, sixty-four per instruction.
+        // Records beyond place 63 go to their rows directly.
         // rec_table_base + rec_offset with the block's part in scalar registers and 32-bit lane
         // arithmetic: a row of places (E * 16 * geom_blocks * 64 of them) is far below 2^32, the
         // sixteen rows of 12-byte records would not fit the GPU's memory otherwise
-        const int64_t blk_base = rec_table_base(v, e, 0) + ((int64_t)blockIdx.x << 6);
-        const uint32_t part_stride = (uint32_t)v.geom_blocks * 64u;
-        const uint32_t row_stride = (uint32_t)v.E * kBinParts * part_stride;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (part_slot[k] == kDeadCell) continue;
             const int part = (int)(part_slot[k] >> 16);
             const unsigned slot = part_slot[k] & 0xFFFFu;
             const unsigned place = place4[k];
-            const int64_t at = blk_base + (int64_t)((uint64_t)(place >> 6) * row_stride +
-                                                    ((uint32_t)part * part_stride + (place & 63u)));
-            v.rec_h[at] = hk[k];
-            if (PACKED) {
-                v.rec_w[at] = (slot << kPackPixBits) | (unsigned)(i0 + k);
+            const uint32_t w = PACKED ? ((slot << kPackPixBits) | (unsigned)(i0 + k)) : (unsigned)(i0 + k);
+            if (place < 64u) {
+                s_h[part][place] = hk[k];
+                s_w[part][place] = w;
+                if (!PACKED) s_s[PACKED ? 0 : part][place] = slot;
             } else {
-                v.rec_w[at] = (unsigned)(i0 + k);
-                v.rec_s[at] = slot;
+                const int64_t at = blk_base + (int64_t)((uint64_t)(place >> 6) * row_stride +
+                                                        ((uint32_t)part * part_stride + (place & 63u)));
+                v.rec_h[at] = hk[k];
+                v.rec_w[at] = w;
+                if (!PACKED) v.rec_s[at] = slot;
             }
         }
     }
@@ -386,6 +399,18 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
         }
     }
     __syncthreads();
+    {
+        // staged rows out: wave w writes the tables w, w + 4, ..., lane <-> place
+        const unsigned lane = threadIdx.x & 63u;
+        for (int part = (int)(threadIdx.x >> 6); part < kBinParts; part += 4) {
+            if (lane < min(s_cnt[part], 64u)) {
+                const int64_t at = blk_base + (int64_t)((uint32_t)part * part_stride + lane);
+                v.rec_h[at] = s_h[part][lane];
+                v.rec_w[at] = s_w[part][lane];
+                if (!PACKED) v.rec_s[at] = s_s[PACKED ? 0 : part][lane];
+            }
+        }
+    }
     if (threadIdx.x < kBinParts)
         v.bin_cnt[((int64_t)e * kBinParts + threadIdx.x) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
     if (threadIdx.x == 64) {

@@ -96,6 +96,7 @@ struct View {
     float depth_min, depth_max;
     double fx, fy, p2m;
     double inv_fx, inv_fy, inv_p2m;   // correctly rounded reciprocals (host division)
+    double inv_fx_wide, inv_fy_wide;  // the same times (1 + 2^-20): the exactness test of div_known
     // scratch (device)
     const EnvState *envs;
     PoseBlock *poses;          // [E] written by the geometry kernel, read by the later kernels

@@ -777,7 +777,6 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
     launch_geometry(lv, *f, packed ? pb : nullptr, stream);
     MARK(1);
     launch_winners(lv, *f, stream);
-    launch_resolve_wrapped(lv, stream);
     MARK(2);
     if (prob_rule) {
         launch_stream(lv, *f, true, nullptr, stream);

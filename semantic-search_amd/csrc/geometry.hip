@@ -810,11 +810,46 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
     }
 }
 
+// numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
+// happens when an update cell with a negative index wraps onto another update cell
+// (mapper.py:326-338 masks only the upper bounds).  At most four update pixels can reach one
+// wrapped cell -- one per sign quadrant of (row, col) -- so frames with wrapped cells record
+// each update pixel in its quadrant slot of the cell; the highest pixel index owns the cell
+// and the others are flagged.  One block per env (the winner block of the env that finishes
+// last): slots are written, then compared.
+__device__ inline void resolve_wrapped(const View &v, int e, unsigned n, int write_target) {
+    const int64_t fbase = (int64_t)e * v.N;
+    int2 *list = reinterpret_cast<int2 *>(v.winners) + fbase;
+    int32_t *quad = v.quad + e * v.quad_stride;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const int2 pc = list[i];
+        const uint32_t pw = (uint32_t)pc.x;
+        const int q = ((pw & kRowNegBit) ? 2 : 0) | ((pw & kColNegBit) ? 1 : 0);
+        quad[4ll * pc.y + q] = (int)(pw & kPixMask) + 1;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const int2 pc = list[i];
+        const int pix = (int)((uint32_t)pc.x & kPixMask);
+        const int4 qs = *reinterpret_cast<const int4 *>(quad + 4ll * pc.y);
+        const int owner = max(max(qs.x, qs.y), max(qs.z, qs.w));
+        if (owner != pix + 1) {
+            list[i].x = (int)((uint32_t)pc.x | kLostBit);
+            if (write_target) v.wflag[fbase + pix] = 0;
+        }
+    }
+}
+
 // Frames whose predicted cell box fits the 16 tables and holds every live pixel are read as
 // per-table record ranges; the others (spilled) are scanned pixel by pixel, once per table.
+// Only a frame whose cell box reaches below zero, or a spilled one, can hold wrapped cells: the
+// winner blocks of such a frame publish their part of the update list (device-scope release), take
+// a ticket, and the block that takes the last one resolves the wrapped cells of the whole list.
+// Every block of a frame sees the same box and reports, so they agree on whether tickets are taken.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
                                                             int write_target, int write_list) {
     __shared__ WinnerShared sh;
+    __shared__ unsigned int s_last;
     const int e = blockIdx.y;
     FrameHeader *hdr = v.hdr + e;
     // every first load of the block in one group: the latencies overlap instead of adding up
@@ -840,50 +875,23 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         if (sh.frame.err) atomicOr(&hdr->status, sh.frame.err);
     }
     const int32_t box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
+    const bool may_wrap = write_list && (sh.frame.spill || pre.rmin < 0 || pre.cmin < 0);
     if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)
         winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre);
     else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre);
     else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre);
-}
-
-// numpy keeps only the LAST write when one fancy-index assignment names a cell twice, which
-// happens when an update cell with a negative index wraps onto another update cell
-// (mapper.py:326-338 masks only the upper bounds).  At most four update pixels can reach one
-// wrapped cell -- one per sign quadrant of (row, col) -- so frames with wrapped cells record
-// each update pixel in its quadrant slot of the cell; the highest pixel index owns the cell
-// and the others are flagged.  One block per env: slots are written, then compared.
-__global__ __launch_bounds__(1024) void k_resolve_wrapped(View v, int write_target) {
-    const int e = blockIdx.x;
-    const FrameHeader *hdr = v.hdr + e;
-    if (hdr->n_neg == 0) return;
-    const unsigned n = hdr->n_winners;
-    const int64_t fbase = (int64_t)e * v.N;
-    int2 *list = reinterpret_cast<int2 *>(v.winners) + fbase;
-    int32_t *quad = v.quad + e * v.quad_stride;
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-        const int2 pc = list[i];
-        const uint32_t pw = (uint32_t)pc.x;
-        const int q = ((pw & kRowNegBit) ? 2 : 0) | ((pw & kColNegBit) ? 1 : 0);
-        quad[4ll * pc.y + q] = (int)(pw & kPixMask) + 1;
+    if (!may_wrap) return;
+    __syncthreads();   // every thread's list entries and the block's header atomics are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&hdr->pad, 1u) == gridDim.x - 1u ? 1u : 0u;
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-        const int2 pc = list[i];
-        const int pix = (int)((uint32_t)pc.x & kPixMask);
-        const int4 qs = *reinterpret_cast<const int4 *>(quad + 4ll * pc.y);
-        const int owner = max(max(qs.x, qs.y), max(qs.z, qs.w));
-        if (owner != pix + 1) {
-            list[i].x = (int)((uint32_t)pc.x | kLostBit);
-            if (write_target) v.wflag[fbase + pix] = 0;
-        }
-    }
+    if (!s_last) return;
+    __threadfence();
+    if (__hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    resolve_wrapped(v, e, __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), write_target);
 }
-
-void launch_resolve_wrapped(const View &v, hipStream_t s) {
-    const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
-    hipLaunchKernelGGL(k_resolve_wrapped, dim3(v.E), dim3(1024), 0, s, v, prob_rule ? 1 : 0);
-}
-
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
             const bool weighted = v.rule == SSMAP_RULE_PROB_HV;
             if (weighted) mp.unc_map[cell] = unc_v;
             // Up to four update pixels can share a cell through numpy's negative-index wrap, one
-            // per sign quadrant (k_resolve_wrapped recorded them; this thread has the highest
+            // per sign quadrant (resolve_wrapped in the winner kernel recorded them; this thread has the highest
             // pixel, the others were dropped from the list).  numpy applies every statement of
             // the rule to all of them with "the last one wins" among the entries that statement
             // selects, so the pixels are walked in ascending order and each statement keeps the

@@ -60,7 +60,7 @@ struct FrameHeader {
     uint32_t any_goal;                    // goal_decay: some update pixel carries the goal id
     uint32_t any_eroded;                  // goal_decay: the eroded goal mask of this frame has a set cell
     uint32_t n_neg;                       // update cells reached through a negative (wrapped) index
-    uint32_t pad;
+    uint32_t pad;                         // tickets of the winner blocks of a frame that may hold wrapped cells
 };
 
 // What a geometry block reports about its pixels besides the records; the winner kernel folds
@@ -199,7 +199,6 @@ struct EgoTables {
 // launchers (defined in the .hip files)
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s);
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s);
-void launch_resolve_wrapped(const View &v, hipStream_t s);
 void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs_out, hipStream_t s);
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);

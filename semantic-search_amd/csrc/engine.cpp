@@ -282,7 +282,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_hdr, (size_t)v.E));
     v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
-    v.wprob_stride = v.C;   // padding the rows to whole cache lines measured slower
+    v.wprob_stride = v.C;   // padding the rows (to 16 bytes, to whole cache lines) measured slower
     v.local_stride = 4ll * c.max_map_h * c.max_map_w;
     eng->step_bytes = carve_step_scratch(c, v, nullptr);
     TRY_ALLOC(dev_alloc(&eng->d_step, eng->step_bytes));
@@ -363,6 +363,29 @@ int ssmap_set_schema(ssmap_engine *eng, const int32_t *lut, int32_t n, const int
     }
     HIP_TRY(hipMemcpy(eng->d_pool_ids, ids, sizeof(ids), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(eng->d_pool_count, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    {
+        View &v = eng->view;
+        memset(v.pool_pack, 0, sizeof(v.pool_pack));
+        memset(v.pool_mask, 0, sizeof(v.pool_mask));
+        for (int g = 0; g < 6; ++g)
+            for (int k = 0; k < cnt[g]; ++k) {
+                const int c = ids[g * SSMAP_MAX_POOL + k];
+                v.pool_mask[c >> 5] |= 1u << (c & 31);
+            }
+        auto below = [&](int c) {   // pooled classes below c = c's staging slot (the kernel walks upwards)
+            int r = 0;
+            for (int d = 0; d < c; ++d) r += (v.pool_mask[d >> 5] >> (d & 31)) & 1u;
+            return r;
+        };
+        v.pool_slots = below(n);
+        for (int g = 0; g < 6; ++g) {
+            v.pool_pack[12] |= (uint32_t)cnt[g] << (4 * g);
+            for (int k = 0; k < cnt[g]; ++k) {
+                const int at = g * SSMAP_MAX_POOL + k;
+                v.pool_pack[at >> 2] |= (uint32_t)below(ids[at]) << (8 * (at & 3));
+            }
+        }
+    }
     // The pooled confidence of a pixel is its largest probability itself when every goal id is
     // reached through exactly one class and that class is the goal's whole list.
     eng->view.pool_trivial = 1;

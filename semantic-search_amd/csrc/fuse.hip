@@ -15,6 +15,7 @@
 // per-cell entropy / argmax are DPP row reductions.
 #include "ssmap_internal.h"
 #include "rows.h"
+#include <cstring>
 
 namespace ssmap {
 
@@ -57,6 +58,17 @@ struct StreamArgs {
     const int32_t *gt;
 };
 
+// Classes that the goal lists of the reference's SegFormer wrapper name (infer.py:278-292: chair 19,
+// 30, 75; bed 7; plant 17; toilet 65; tv_monitor 143, 130, 141, 89; sofa 23), as a bit per class.
+__host__ __device__ constexpr uint32_t ade_pool_word(int w) {
+    constexpr int ids[] = {19, 30, 75, 7, 17, 65, 143, 130, 141, 89, 23};
+    uint32_t m = 0;
+    for (int id : ids) if ((id >> 5) == w) m |= 1u << (id & 31);
+    return m;
+}
+constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
+    ade_pool_word(0), ade_pool_word(1), ade_pool_word(2), ade_pool_word(3), ade_pool_word(4), 0, 0, 0};
+
 // ---------------------------------------------------------------- register kernel
 // One pixel per thread.  The C class planes of the env's frame are read through one buffer
 // descriptor: lane offset (pixel) in a vector register, plane offset in a scalar register, so
@@ -64,8 +76,9 @@ struct StreamArgs {
 // read once and should not push the map lines out of L2.  (Two or four pixels per thread with
 // wider loads measured slower: the larger register footprint costs more occupancy than the
 // wider requests gain.)
-template <int CT, int MODE>
-__global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
+template <int CT, int MODE, int POOL>
+__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? 2 : 1, CT > 128 ? 2 : 8))) void k_stream_reg(View v, StreamArgs a) {
+    extern __shared__ float s_pool[];   // POOL: [pool_slots][kRegTile], a column per thread
     const int e = blockIdx.y;
     const int t = threadIdx.x;
     const int pix = blockIdx.x * kRegTile + t;
@@ -76,6 +89,18 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
 
+    // the class -> schema table, spread over the lanes (lane l holds entries l, l + 64, ...): asked
+    // for in front of the class planes and looked up with a lane permute at the end, so that no
+    // wave ends on a dependent gather through the saturated memory pipeline
+    constexpr int kLutRegs = (CT + 63) / 64;
+    int lut_reg[kLutRegs];
+    if (a.from_logits) {
+#pragma unroll
+        for (int k = 0; k < kLutRegs; ++k) {
+            const int idx = (t & 63) + 64 * k;
+            lut_reg[k] = v.lut[idx < CT ? idx : 0];
+        }
+    }
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -114,25 +139,43 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
             hsum = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + 1e-6f), hsum);   // log2
             bi = x[c] == inv_s ? c : bi;
         }
-        const int sid = v.lut[bi];
+        int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
+#pragma unroll
+        for (int k = 1; k < kLutRegs; ++k) {
+            const int other = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[k]);
+            sid = (bi >> 6) == k ? other : sid;
+        }
         float conf = inv_s;
-        if (!a.pool_trivial && sid >= 3 && sid <= 8) {
+        if (POOL) {
             // probability mass of the goal's listed model classes, added in list order like the
             // reference's probs[ids].sum(axis=0) (infer.py:109-118, 318-327); an empty list gives 0.
-            // The list entries are wave-uniform, so a class is picked by a compare-and-select
-            // chain over the registers instead of a per-lane indexed read.
-            for (int g = 0; g < 6; ++g) {
-                if (!__ballot(sid == g + 3)) continue;
-                const int n = __builtin_amdgcn_readfirstlane(v.pool_count[g]);
-                float acc = 0.0f;
-                for (int k = 0; k < n; ++k) {
-                    const int idx = __builtin_amdgcn_readfirstlane(v.pool_ids[g * SSMAP_MAX_POOL + k]);
-                    float pv = 0.0f;
+            // Every class that some goal pools parks its probability in the thread's LDS column
+            // (membership is a scalar bit test: no vector work for the other classes; slots are
+            // numbered in the order of this walk); a goal lane then adds its list's slots in list
+            // order.  The slot numbers and list lengths travel by value with the kernel arguments.
+            if (__ballot(sid >= 3 && sid <= 8)) {
+                int pj = 0;
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) pv = c == idx ? x[c] : pv;
-                    acc = k == 0 ? pv : acc + pv;
+                for (int c = 0; c < CT; ++c) {
+                    // POOL 2: the lists are those of the reference's SegFormer wrapper (checked by the
+                    // launcher), so membership is known when the loop is unrolled; otherwise one
+                    // scalar test and branch per class
+                    const bool member = POOL == 2 ? ((kAdePoolMask[c >> 5] >> (c & 31)) & 1u) != 0u
+                                                  : ((v.pool_mask[c >> 5] >> (c & 31)) & 1u) != 0u;
+                    if (member) { s_pool[pj * kRegTile + t] = x[c]; ++pj; }
                 }
-                conf = sid == g + 3 ? acc : conf;
+                for (int g = 0; g < 6; ++g) {
+                    if (!__ballot(sid == g + 3)) continue;
+                    const int n = (int)((v.pool_pack[12] >> (4 * g)) & 0xFu);
+                    float acc = 0.0f;
+                    for (int k = 0; k < n; ++k) {
+                        const int at = g * SSMAP_MAX_POOL + k;
+                        const int slot_k = (int)((v.pool_pack[at >> 2] >> (8 * (at & 3))) & 0xFFu);
+                        const float pv = s_pool[slot_k * kRegTile + t];
+                        acc = k == 0 ? pv : acc + pv;
+                    }
+                    conf = sid == g + 3 ? acc : conf;
+                }
             }
         }
         if (active) {
@@ -163,7 +206,8 @@ __global__ __launch_bounds__(kRegTile) void k_stream_reg(View v, StreamArgs a) {
     __shared__ int s_slot[kRegTile / 64][kLdsRows];
     if (!(CT % 4 == 0 && CT <= 64)) {
         // wide rows: the staging rows would cost more than they save (150 classes measured 6 %
-        // slower through LDS); the owner writes its own row with the widest aligned vector
+        // slower through LDS, rows padded to 16 bytes and written as float4 2 % slower); the owner
+        // writes its own row with the widest vector that divides the row
         if (slot >= 0) {
             float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
 #pragma unroll
@@ -474,12 +518,23 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     }
 }
 
+template <int CT, int POOL>
+static void launch_reg_pool(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
+    dim3 grid((v.N + kRegTile - 1) / kRegTile, v.E);
+    const size_t lds = POOL ? (size_t)(v.pool_slots > 0 ? v.pool_slots : 1) * kRegTile * sizeof(float) : 0;
+    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+    else hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+}
 template <int CT>
 static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
-    dim3 grid((v.N + kRegTile - 1) / kRegTile, v.E);
-    if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0>), grid, dim3(kRegTile), 0, s, v, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1>), grid, dim3(kRegTile), 0, s, v, a);
-    else hipLaunchKernelGGL((k_stream_reg<CT, 2>), grid, dim3(kRegTile), 0, s, v, a);
+    // the pooled confidence needs its LDS columns only when some goal pools more than its own class
+    if (a.from_logits && !a.pool_trivial) {
+        if (CT == 150 && memcmp(v.pool_mask, kAdePoolMask, sizeof(kAdePoolMask)) == 0) launch_reg_pool<CT, CT == 150 ? 2 : 1>(mode, s, v, a);
+        else launch_reg_pool<CT, 1>(mode, s, v, a);
+    } else {
+        launch_reg_pool<CT, 0>(mode, s, v, a);
+    }
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {

@@ -131,6 +131,12 @@ struct View {
     const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
     const int32_t *pool_count; // [6]
     int32_t pool_trivial;      // no goal id pools more than one class
+    // for the register streaming kernel, by value: pool_mask bit c = class c is in some list; its
+    // staging slot = number of such classes below c; pool_pack byte g * SSMAP_MAX_POOL + k = slot of the
+    // k-th class of goal g's list, word 12 = six 4-bit list lengths; pool_slots = classes in lists
+    uint32_t pool_mask[SSMAP_MAX_CLASSES / 32];
+    uint32_t pool_pack[13];
+    int32_t pool_slots;
     int32_t *path_cells;       // [E][path_cap] cells of the agent's trail (path overlay)
     uint32_t *path_count;      // [E]
     int64_t path_cap;          // max_map_h * max_map_w

@@ -9,7 +9,6 @@
 
 #define CHECK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); exit(1); } } while (0)
 
-constexpr int C = 40;
 
 __global__ __launch_bounds__(256) void k_linear(const float4 *in, float *out, size_t n4) {
     float acc = 0.0f;
@@ -32,7 +31,7 @@ __global__ __launch_bounds__(256) void k_linear_chunk(const float4 *in, float *o
     if (acc == 12345.678f) out[0] = acc;
 }
 
-template <int PX, int MATH, int NT>
+template <int C, int PX, int MATH, int NT>
 __global__ __launch_bounds__(256) void k_planes(const float *in, float *out, int N) {
     typedef float VecF __attribute__((ext_vector_type(PX)));
     const int e = blockIdx.y;
@@ -72,6 +71,73 @@ __global__ __launch_bounds__(256) void k_planes(const float *in, float *out, int
     *reinterpret_cast<VecF *>(out + (size_t)e * N + pix) = r;
 }
 
+// The engine's stage-1 arithmetic step by step (FLAGS bits): 1 = buffer loads with scalar plane
+// offsets, 2 = the reference-rounding softmax (exp2 / log2 builtins, no contraction) with argmax,
+// 4 = three per-pixel outputs (nontemporal) instead of one, 8 = class table lookup (global gather)
+template <int C, int FLAGS>
+__device__ __forceinline__ void real_body(const float *in, float *out, int *out_i, float *out2, const int *lut, int N, float inv_t) {
+    const int e = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= N) return;
+    float x[C];
+    if (FLAGS & 1) {
+        const int plane_bytes = N * 4;
+        const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(in + ((size_t)e * C) * N), 0, C * plane_bytes, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, pix * 4, c * plane_bytes, 2));
+    } else {
+        const float *src = in + (size_t)e * C * N + pix;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = __builtin_nontemporal_load(src + (size_t)c * N);
+    }
+    float h = 0.0f, conf = 0.0f;
+    int bi = 0;
+    if (FLAGS & 2) {
+#pragma clang fp contract(off)
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { x[c] *= inv_t; m = fmaxf(m, x[c]); }
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { x[c] = __builtin_amdgcn_exp2f((x[c] - m) * 1.44269504088896341f); s += x[c]; }
+        const float inv_s = 1.0f / s;
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) {
+            x[c] *= inv_s;
+            h = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + 1e-6f), h);
+            bi = x[c] == inv_s ? c : bi;
+        }
+        conf = inv_s;
+    } else {
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { x[c] *= 0.3125f; m = fmaxf(m, x[c]); }
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { x[c] = __expf(x[c] - m); s += x[c]; }
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { x[c] *= inv; h += x[c] * __logf(x[c] + 1e-6f); }
+        conf = inv;
+    }
+    if (FLAGS & 8) bi = lut[bi];
+    const size_t o = (size_t)e * N + pix;
+    if (FLAGS & 4) {
+        __builtin_nontemporal_store(h, out + o);
+        __builtin_nontemporal_store(bi, out_i + o);
+        __builtin_nontemporal_store(conf, out2 + o);
+    } else {
+        out[o] = h + conf + (float)bi;
+    }
+}
+
+template <int C, int FLAGS, int W>
+__global__ __launch_bounds__(256, W) void k_real(const float *in, float *out, int *out_i, float *out2, const int *lut, int N, float inv_t) {
+    real_body<C, FLAGS>(in, out, out_i, out2, lut, N, inv_t);
+}
+
 template <typename F>
 static float time_it(F launch, int reps = 20) {
     hipEvent_t a, b;
@@ -87,8 +153,9 @@ static float time_it(F launch, int reps = 20) {
     return ms / reps * 1e3f;
 }
 
-int main() {
-    const int E = 16, N = 640 * 480;
+template <int C>
+static void run_planes(int E) {
+    const int N = 640 * 480;
     const size_t n = (size_t)E * C * N;
     float *in, *out;
     CHECK(hipMalloc(&in, n * 4));
@@ -96,20 +163,22 @@ int main() {
     CHECK(hipMemset(in, 0, n * 4));
     const double gb = n * 4 / 1e9;
     float us;
-    for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
-        us = time_it([&] { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, (const float4 *)in, out, n / 4); });
-        printf("linear float4 grid-stride %5d blocks: %7.1f us %7.1f GB/s\n", blocks, us, gb / us * 1e6);
-    }
-    for (int blocks : {1024, 2048, 4800}) {
-        us = time_it([&] { hipLaunchKernelGGL(k_linear_chunk, dim3(blocks), dim3(256), 0, 0, (const float4 *)in, out, n / 4); });
-        printf("linear float4 chunked     %5d blocks: %7.1f us %7.1f GB/s\n", blocks, us, gb / us * 1e6);
-    }
 #define RUN(PX, MATH, NT) \
-    us = time_it([&] { hipLaunchKernelGGL((k_planes<PX, MATH, NT>), dim3(N / PX / 256, E), dim3(256), 0, 0, in, out, N); }); \
-    printf("planes PX=%d math=%d nt=%d: %7.1f us %7.1f GB/s\n", PX, MATH, NT, us, gb / us * 1e6);
-    RUN(1, 0, 0) RUN(2, 0, 0) RUN(4, 0, 0)
-    RUN(1, 0, 1) RUN(2, 0, 1) RUN(4, 0, 1)
-    RUN(1, 1, 0) RUN(2, 1, 0) RUN(4, 1, 0)
-    RUN(1, 1, 1) RUN(2, 1, 1) RUN(4, 1, 1)
+    us = time_it([&] { hipLaunchKernelGGL((k_planes<C, PX, MATH, NT>), dim3(N / PX / 256, E), dim3(256), 0, 0, in, out, N); }); \
+    printf("C=%d planes PX=%d math=%d nt=%d: %7.1f us %7.1f GB/s\n", C, PX, MATH, NT, us, gb / us * 1e6);
+    RUN(1, 0, 1) RUN(1, 1, 1)
+#undef RUN
+    int *out_i, *lut; float *out2;
+    CHECK(hipMalloc(&out_i, (size_t)E * N * 4)); CHECK(hipMalloc(&out2, (size_t)E * N * 4)); CHECK(hipMalloc(&lut, 1024)); CHECK(hipMemset(lut, 0, 1024));
+#define REAL(F, W) \
+    us = time_it([&] { hipLaunchKernelGGL((k_real<C, F, W>), dim3(N / 256, E), dim3(256), 0, 0, in, out, out_i, out2, lut, N, 0.3125f); }); \
+    printf("C=%d real flags=%2d minwaves=%d: %7.1f us %7.1f GB/s\n", C, F, W, us, gb / us * 1e6);
+    REAL(0, 1) REAL(0, 2) REAL(0, 3) REAL(2, 1) REAL(2, 2) REAL(2, 3) REAL(7, 2) REAL(7, 3) REAL(15, 2) REAL(15, 3)
+#undef REAL
+    CHECK(hipFree(in)); CHECK(hipFree(out));
+}
+
+int main() {
+    run_planes<150>(16);
     return 0;
 }

@@ -194,6 +194,14 @@ int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature,
                  int32_t *semantic, float *semantic_unc, float *semantic_max_prob,
                  float *probs_out, void *stream);
 
+/* The two map questions of the shortest-path policy's found override (env.py:564-605), for every
+ * env, answered from the maps where they lie, after the last ssmap_step: in_disk[e] = some gt_map
+ * cell inside the found disk around the robot cell of that step carries the goal's schema id
+ * (env.py:581-593; the disk is the one the found decision uses), anywhere[e] = some gt_map cell at
+ * all does (env.py:600, 604).  HOST arrays [E]; either may be NULL (its scan is then skipped).
+ * Waits for `stream`. */
+int ssmap_gt_goal_query(ssmap_engine *eng, int32_t *in_disk, int32_t *anywhere, void *stream);
+
 /* Waits for `stream`, then copies per-env results of the last step to HOST arrays [E]:
  * found (1 = is_found True, 0 = None), status (SSMAP_ENV_* bits), n_updates (K). */
 int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status,

@@ -18,7 +18,7 @@ ENV_INDEX_ERROR = 1
 
 EXPORTS = ("ssmap_create", "ssmap_destroy", "ssmap_set_schema", "ssmap_set_palette",
            "ssmap_set_params", "ssmap_bind_env", "ssmap_step", "ssmap_step_noalloc", "ssmap_stage1",
-           "ssmap_read_results", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
+           "ssmap_read_results", "ssmap_gt_goal_query", "ssmap_update_list", "ssmap_profile_begin", "ssmap_profile_read",
            "ssmap_set_egomap", "ssmap_ego_maps", "ssmap_set_nb_model", "ssmap_path_append", "ssmap_path_paint", "ssmap_last_error", "ssmap_version")
 
 
@@ -92,6 +92,7 @@ def load():
     lib.ssmap_step_noalloc.argtypes = [vp, C.POINTER(Frames), vp]
     lib.ssmap_stage1.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.ssmap_read_results.argtypes = [vp, vp, vp, vp, vp]
+    lib.ssmap_gt_goal_query.argtypes = [vp, vp, vp, vp]
     lib.ssmap_update_list.argtypes = [vp, i32, C.POINTER(vp)]
     lib.ssmap_profile_begin.argtypes = [vp, i32]
     lib.ssmap_profile_read.argtypes = [vp, vp, vp, vp]

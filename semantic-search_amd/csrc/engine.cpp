@@ -158,6 +158,8 @@ struct ssmap_engine {
     FrameHeader *d_hdr = nullptr;
     std::vector<FrameHeader> h_hdr;
     int32_t *d_lut = nullptr, *d_pool_ids = nullptr, *d_pool_count = nullptr, *d_disk = nullptr;
+    int32_t *d_query = nullptr;            // [E][2] answers of ssmap_gt_goal_query
+    std::vector<int32_t> h_query;
     uint8_t *d_palette = nullptr;
     NbModel *d_nb = nullptr;               // [6] naive-Bayes models of the stubborn rule, by goal id - 3
     bool nb_set[6] = {};
@@ -171,6 +173,7 @@ struct ssmap_engine {
     unsigned char *d_static = nullptr;     // this device's copy of the file-scope array, for ssmap_step_noalloc
     size_t step_bytes = 0;
     const int32_t *last_list = nullptr;    // update list of the last step (either home)
+    bool stepped = false;                  // some step has run (its poses and goal ids are on the device)
     // egocentric observation maps (ssmap_set_egomap / ssmap_ego_maps)
     EgoTables *d_ego = nullptr;
     std::vector<EgoTables> h_ego;          // one element once configured
@@ -217,7 +220,7 @@ void ssmap_destroy(ssmap_engine *eng) {
     hipFree(eng->d_envs); hipFree(eng->d_poses); hipFree(eng->d_hdr);
     hipFree(eng->d_step); hipFree(v.quad);
     for (int i = 0; i < 2; ++i) { hipFree(v.overlay[i]); hipFree(v.overlay_count[i]); }
-    hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count);
+    hipFree(eng->d_lut); hipFree(eng->d_pool_ids); hipFree(eng->d_pool_count); hipFree(eng->d_query);
     hipFree(eng->d_disk); hipFree(eng->d_palette); hipFree(eng->d_ego);
     hipFree(eng->d_nb); hipFree(eng->d_nb_probs);
     hipFree(v.path_cells); hipFree(v.path_count);
@@ -308,6 +311,8 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
     TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
     TRY_ALLOC(dev_alloc(&eng->d_pool_count, (size_t)6));
+    TRY_ALLOC(dev_alloc(&eng->d_query, (size_t)2 * v.E));
+    eng->h_query.assign((size_t)2 * v.E, 0);
     v.path_cap = (int64_t)c.max_map_h * c.max_map_w;
     TRY_ALLOC(dev_alloc(&v.path_cells, (size_t)v.E * v.path_cap));
     TRY_ALLOC(dev_alloc(&v.path_count, (size_t)v.E));
@@ -816,6 +821,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
 #undef MARK
     HIP_TRY(hipGetLastError());
     v.cur_overlay ^= 1;
+    eng->stepped = true;
     return SSMAP_OK;
 }
 
@@ -853,6 +859,26 @@ int ssmap_read_results(ssmap_engine *eng, int32_t *found, uint32_t *status, int3
         if (found) found[e] = eng->h_hdr[e].found;
         if (status) status[e] = eng->h_hdr[e].status;
         if (n_updates) n_updates[e] = (int32_t)eng->h_hdr[e].n_winners;
+    }
+    return SSMAP_OK;
+}
+
+int ssmap_gt_goal_query(ssmap_engine *eng, int32_t *in_disk, int32_t *anywhere, void *stream_v) {
+    if (!eng) return fail(SSMAP_ERR_INVALID_ARG, "null argument");
+    if (!eng->stepped || !eng->d_disk) return fail(SSMAP_ERR_NOT_READY, "ssmap_gt_goal_query before any ssmap_step");
+    int rc = check_ready(eng);
+    if (rc != SSMAP_OK) return rc;
+    const int what = (in_disk ? 1 : 0) | (anywhere ? 2 : 0);
+    if (!what) return SSMAP_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    launch_gt_goal(eng->view, what, eng->d_query, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(eng->h_query.data(), eng->d_query, sizeof(int32_t) * 2 * eng->cfg.n_envs,
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int e = 0; e < eng->cfg.n_envs; ++e) {
+        if (in_disk) in_disk[e] = eng->h_query[2 * e];
+        if (anywhere) anywhere[e] = eng->h_query[2 * e + 1];
     }
     return SSMAP_OK;
 }

@@ -573,6 +573,39 @@ void launch_path_paint(const View &v, uint32_t max_count, hipStream_t s) {
     hipLaunchKernelGGL(k_path_paint, dim3(blocks < 64u ? blocks : 64u, v.E), dim3(256), 0, s, v);
 }
 
+// Does the ground-truth map hold the goal id inside the found disk around the robot cell
+// (what & 1), anywhere (what & 2)?  (env.py:581-604.)  One block per env; out[2 e], out[2 e + 1].
+__global__ __launch_bounds__(1024) void k_gt_goal(View v, int what, int32_t *__restrict__ out) {
+    const int e = blockIdx.x;
+    const ssmap_env_maps mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const uint32_t goal = (uint32_t)pb.goal_id;
+    // without probabilistic mapping the reference's gt_map is its semantic_map (mapper.py:257)
+    const uint32_t *gt = mp.gt_map ? mp.gt_map : mp.semantic_map;
+    int in_disk = 0, anywhere = 0;
+    if (what & 2) {
+        const int n = mp.map_h * mp.map_w;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) anywhere |= gt[i] == goal;
+    }
+    if (what & 1) {
+        const int R = v.disk_radius, side = 2 * R + 1;
+        for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
+            const int dr = i / side - R, dc = i % side - R;
+            const int half = v.disk_hw[dr < 0 ? -dr : dr];
+            const int row = pb.robot_row + dr, col = pb.robot_col + dc;
+            if (half >= 0 && dc >= -half && dc <= half && row >= 0 && row < mp.map_h && col >= 0 && col < mp.map_w)
+                in_disk |= gt[row * mp.map_w + col] == goal;
+        }
+    }
+    in_disk = __syncthreads_or(in_disk);
+    anywhere = __syncthreads_or(anywhere);
+    if (threadIdx.x == 0) { out[2 * e] = in_disk ? 1 : 0; out[2 * e + 1] = anywhere ? 1 : 0; }
+}
+
+void launch_gt_goal(const View &v, int what, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gt_goal, dim3(v.E), dim3(1024), 0, s, v, what, out);
+}
+
 void launch_found(const View &v, hipStream_t s) {
     hipLaunchKernelGGL(k_found, dim3(kFoundBlocks, v.E), dim3(kFoundThreads), 0, s, v);
 }

@@ -209,6 +209,7 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s);
 void launch_found(const View &v, hipStream_t s);
+void launch_gt_goal(const View &v, int what, int32_t *out, hipStream_t s);
 void launch_path_paint(const View &v, uint32_t max_count, hipStream_t s);
 void launch_ego_maps(const View &v, const EgoPose *host_poses, const EgoTables *d_tables, const EgoTables &h_tables,
                      uint8_t *ego_small, uint8_t *ego_large, float *unc_small, float *unc_large, hipStream_t s);

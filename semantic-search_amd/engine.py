@@ -402,6 +402,20 @@ class MapEngine:
                                                     n_upd.ctypes.data, C.c_void_p(stream)))
         return found.astype(bool), status, n_upd
 
+    def gt_goal_query(self, in_disk: bool = True, anywhere: bool = True):
+        """The two map questions of the shortest-path policy's found override (env.py:581-604), per
+        env, after the last `step`: does gt_map hold the goal's id inside the found disk around the
+        robot cell; does it hold it anywhere.  Returns (in_disk[E] or None, anywhere[E] or None) as
+        host bool arrays; waits for the current stream."""
+        E = self.n_envs
+        a = np.zeros(E, dtype=np.int32) if in_disk else None
+        b = np.zeros(E, dtype=np.int32) if anywhere else None
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _capi.check(self.lib.ssmap_gt_goal_query(self._h, a.ctypes.data if in_disk else None,
+                                                     b.ctypes.data if anywhere else None, C.c_void_p(stream)))
+        return (a.astype(bool) if in_disk else None, b.astype(bool) if anywhere else None)
+
     def profile_begin(self, max_steps: int):
         _capi.check(self.lib.ssmap_profile_begin(self._h, int(max_steps)))
 

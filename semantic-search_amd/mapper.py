@@ -141,6 +141,47 @@ def _load_nb_models(nb_models, model_name):
     return dict(nb_models)
 
 
+def sp_found_override(true_found, in_disk, anywhere, distance_to_vp, success_distance, fp_found):
+    """The shortest-path policy's override of the found decision (env.py:574-605), element-wise
+    over envs.  `true_found` = the mapper's decision, `in_disk` / `anywhere` = the goal id lies in
+    gt_map inside the found disk / at all, `fp_found` = the episode's false-positive latch so far.
+    Returns (is_found, fp_found, fn_found): fn_found is None where the robot is not within
+    `success_distance` of the viewpoint (the reference leaves its flag untouched there)."""
+    true_found = np.asarray(true_found, dtype=bool)
+    in_disk = np.asarray(in_disk, dtype=bool)
+    anywhere = np.asarray(anywhere, dtype=bool)
+    fp = np.asarray(fp_found, dtype=bool) | (true_found & ~in_disk)          # env.py:580-594
+    near = np.asarray(distance_to_vp, dtype=np.float64) < success_distance   # env.py:598
+    fn = np.where(near, anywhere & ~true_found & ~fp, None)                  # env.py:599-603
+    return near & anywhere, fp, fn                                           # env.py:575, 604-605
+
+
+class SpPolicyFoundOverride:
+    """State and call of that override for one SemanticMapper, as MappingObjNavEnv keeps it
+    (`_sp_fp_found`, `_sp_fn_found`, reset with the episode: env.py:317-318, 564-605; they end up as the
+    episode's `fp_found` / `fn_found`, env.py:724-734)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.sp_fp_found = False
+        self.sp_fn_found = False
+
+    def __call__(self, mapper, true_found, distance_to_vp, success_distance) -> bool:
+        """After `mapper.update_map(...)` returned `true_found`: the overridden decision.  The two
+        map questions are answered on the GPU from the maps in place (only those the branch reads)."""
+        near = distance_to_vp < success_distance
+        in_disk, anywhere = mapper._engine.gt_goal_query(in_disk=bool(true_found), anywhere=bool(near))
+        found, fp, fn = sp_found_override([bool(true_found)], [True] if in_disk is None else in_disk,
+                                          [False] if anywhere is None else anywhere, [distance_to_vp],
+                                          success_distance, [self.sp_fp_found])
+        self.sp_fp_found = bool(fp[0])
+        if fn[0] is not None:
+            self.sp_fn_found = bool(fn[0])
+        return bool(found[0])
+
+
 class SemanticMapper:
     def __init__(
         self,

@@ -133,6 +133,11 @@ typedef struct ssmap_frames {
     const double  *agent_pose;         /* HOST [E][7]: x y z qw qx qy qz (task.py:190-193) */
     const double  *camera_pose;        /* HOST [E][7] */
     const int32_t *goal_sem_id;        /* HOST [E]: goal2sem_id[objectgoal][0] */
+    const uint8_t *skip;               /* HOST [E] or NULL: non-zero = env e has no frame in this batch
+                                          (its update_map was not called): its maps, pose, path and
+                                          hv overlay stay as they are, its results read found 0,
+                                          status 0, n_updates 0; its slices of the arrays above are
+                                          not read (its stage-1 outputs are unspecified) */
 } ssmap_frames;
 
 /* SemanticMapper.__init__ (mapper.py:49-191): validates the config, allocates scratch. */

@@ -10,5 +10,6 @@ batch of environments held on one GPU.  Both call the HIP library built by
 from semantic_search_amd import _capi  # noqa: F401
 from semantic_search_amd.engine import MapEngine, RuleParams, colormap, focal_lengths, map_size  # noqa: F401
 from semantic_search_amd.mapper import SemanticMapper, SpPolicyFoundOverride, sp_found_override  # noqa: F401
+from semantic_search_amd.group import MapperGroup  # noqa: F401
 
-__all__ = ["SemanticMapper", "SpPolicyFoundOverride", "sp_found_override", "MapEngine", "RuleParams", "colormap", "focal_lengths", "map_size"]
+__all__ = ["SemanticMapper", "MapperGroup", "SpPolicyFoundOverride", "sp_found_override", "MapEngine", "RuleParams", "colormap", "focal_lengths", "map_size"]

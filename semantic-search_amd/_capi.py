@@ -54,7 +54,7 @@ class Frames(C.Structure):
                 ("temperature", C.c_float), ("semantic", C.c_void_p),
                 ("semantic_unc", C.c_void_p), ("semantic_max_prob", C.c_void_p),
                 ("semantic_gt", C.c_void_p), ("agent_pose", C.c_void_p),
-                ("camera_pose", C.c_void_p), ("goal_sem_id", C.c_void_p)]
+                ("camera_pose", C.c_void_p), ("goal_sem_id", C.c_void_p), ("skip", C.c_void_p)]
 
 
 _lib = None

@@ -152,6 +152,7 @@ struct ssmap_engine {
     EnvState *d_envs = nullptr;
     PoseBlock *d_poses = nullptr;
     std::vector<PoseBlock> h_poses;       // this step's poses when they travel as kernel arguments
+    std::vector<PoseBlock> last_poses;    // pose of every env's last frame (a skipped env keeps it)
     PoseBlock *h_ring[kPoseRing] = {};    // pinned staging otherwise (more than kPosePack envs)
     hipEvent_t pose_done[kPoseRing] = {};
     int ring = 0;
@@ -325,6 +326,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_zero(eng->d_lut, SSMAP_MAX_CLASSES * sizeof(int32_t)));
 #undef TRY_ALLOC
     eng->h_poses.assign(c.n_envs, PoseBlock{});
+    eng->last_poses.assign(c.n_envs, PoseBlock{});
     for (int i = 0; i < kPoseRing && c.n_envs > kPosePack; ++i) {
         if (hipHostMalloc(reinterpret_cast<void **>(&eng->h_ring[i]), sizeof(PoseBlock) * v.E) != hipSuccess ||
             hipEventCreateWithFlags(&eng->pose_done[i], hipEventDisableTiming) != hipSuccess) {
@@ -771,6 +773,12 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
         const double *ag = f->agent_pose + 7 * e, *cam = f->camera_pose + 7 * e;
         const ssmap_env_maps &mp = eng->envs[e].maps;
         PoseBlock &b = pb[e];
+        if (f->skip && f->skip[e]) {   // no frame for this env: its last pose stays on the device
+            b = eng->last_poses[e];
+            b.skip = 1;
+            b.box[0] = 1; b.box[1] = 0; b.box[2] = 1; b.box[3] = 0;
+            continue;
+        }
         qmatrix(qmul(Quat{cam[3], cam[4], cam[5], cam[6]}, eng->flip_cam), b.rot);
         b.trans[0] = cam[0]; b.trans[1] = cam[1]; b.trans[2] = cam[2];
         b.h_cut = cam[1] + c.height_cutoff_m;
@@ -778,8 +786,9 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
         b.robot_row = clamp_cell(std::floor((ag[2] - mp.lower[2]) / c.pixel2meter));
         b.robot_col = clamp_cell(std::floor((ag[0] - mp.lower[0]) / c.pixel2meter));
         b.goal_id = f->goal_sem_id[e];
-        b.pad = 0;
+        b.skip = 0;
         predict_box(c, mp, b);
+        eng->last_poses[e] = b;
     }
 
     if (!packed) {

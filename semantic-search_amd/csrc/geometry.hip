@@ -281,9 +281,10 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             h.n_neg = 0;
             h.pad = 0;
             v.hdr[e] = h;
-            v.overlay_count[v.cur_overlay][e] = 0;
+            if (!pb.skip) v.overlay_count[v.cur_overlay][e] = 0;   // (a skipped env's overlay list is carried over)
         }
     }
+    if (pb.skip) return;   // no frame for this env: nothing is read, no record, no report (whole block)
     const int rmin = pb.box[0], rmax = pb.box[1], cmin = pb.box[2], cmax = pb.box[3];
     const BinFrame f = bin_frame_box(pb.box);
     if (threadIdx.x < kBinParts) s_cnt[threadIdx.x] = 0;
@@ -852,6 +853,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     __shared__ unsigned int s_last;
     const int e = blockIdx.y;
     FrameHeader *hdr = v.hdr + e;
+    if (v.poses[e].skip) return;   // no frame for this env (its header says zero update cells)
     // every first load of the block in one group: the latencies overlap instead of adding up
     const ReportRegs rep = load_reports(v, e);
     WinnerPre pre;

@@ -35,7 +35,7 @@ struct PoseBlock {
     double agent[3];      // agent position
     int32_t robot_row, robot_col;   // world2map(agent position)
     int32_t goal_id;      // schema id of the goal
-    int32_t pad;
+    int32_t skip;         // the env has no frame in this step: every kernel leaves it alone
     // cell box {rmin, rmax, cmin, cmax} predicted to hold every live pixel of the frame: the camera
     // frustum up to depth_max, padded, cut to the indexable range [-dim, dim).  rmin > rmax: none.
     int32_t box[4];

@@ -332,8 +332,10 @@ class MapEngine:
              temperature: float = 1.0, semantic: Optional[torch.Tensor] = None,
              semantic_unc: Optional[torch.Tensor] = None,
              semantic_max_prob: Optional[torch.Tensor] = None,
-             semantic_gt: Optional[torch.Tensor] = None, static_scratch: bool = False):
-        """Enqueues stages 1-5 for all envs on the current stream.  With `static_scratch` the
+             semantic_gt: Optional[torch.Tensor] = None, static_scratch: bool = False, skip=None):
+        """Enqueues stages 1-5 for all envs on the current stream.  `skip` (host bools [E]) names envs
+        without a frame in this batch: their maps and state stay untouched, their results read
+        found False, status 0, 0 updates.  With `static_scratch` the
         allocation-free entry point runs the step (per-step scratch in the library's file-scope
         device array; raises when this engine's scratch does not fit).  Tensors are [E, ...] on the
         engine's device, contiguous; `depth` is modified in place (sentinels zeroed).  Poses are
@@ -361,6 +363,10 @@ class MapEngine:
         cp = np.ascontiguousarray(np.asarray(camera_pose, dtype=np.float64).reshape(E, 7))
         gi = np.ascontiguousarray(np.asarray(goal_sem_ids, dtype=np.int32).reshape(E))
         fr.agent_pose, fr.camera_pose, fr.goal_sem_id = ap.ctypes.data, cp.ctypes.data, gi.ctypes.data
+        sk = None
+        if skip is not None:
+            sk = np.ascontiguousarray(np.asarray(skip).reshape(E).astype(np.uint8))
+            fr.skip = sk.ctypes.data
         with torch.cuda.device(self.device):
             if self.params.dirty:
                 pk = self.params.pack()

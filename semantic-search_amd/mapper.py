@@ -183,6 +183,8 @@ class SpPolicyFoundOverride:
 
 
 class SemanticMapper:
+    _e = 0   # this mapper's env inside its engine (a view of a MapperGroup has its own)
+
     def __init__(
         self,
         num_semantic_classes: int,
@@ -331,68 +333,84 @@ class SemanticMapper:
                 self._engine.reset_env(0, self.map_bounds)
                 self._bound = True
 
-    def update_map(self, obs: Dict[str, np.ndarray], auxillary_angle=None):
-        depth = obs["depth"]
-        h, w = depth.shape
-        eng = self._ensure_engine(h, w)
-        self._sync_params(eng)
-        dev = eng.device
+    def _inputs(self, obs, dev):
+        """One frame's arrays as device tensors (no batch axis) under the engine's keyword names,
+        and the goal's schema id.  numpy arrays like the reference's callers pass, or torch tensors
+        (a segmentation model's outputs that are already on the GPU skip the round trip through the
+        host)."""
         goal_id = int(self.goal2sem_id[obs["objectgoal"]][0])
 
         def up(key, dtype):
-            # numpy arrays like the reference's callers pass, or torch tensors (a segmentation
-            # model's outputs that are already on the GPU skip the round trip through the host)
             if key not in obs or obs[key] is None:
                 return None
             val = obs[key]
             if isinstance(val, torch.Tensor):
-                return val.detach().to(device=dev, dtype=_TORCH_DTYPES[dtype]).unsqueeze(0).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(val, dtype=dtype)).to(dev).unsqueeze(0).contiguous()
+                return val.detach().to(device=dev, dtype=_TORCH_DTYPES[dtype]).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(val, dtype=dtype)).to(dev)
 
-        d_depth = up("depth", np.float32)
-        kwargs = {}
+        tens = {"depth": up("depth", np.float32)}
         if self.probablistic_mapping:
-            kwargs["semantic_gt"] = up("semantic_gt", np.int32)
+            tens["semantic_gt"] = up("semantic_gt", np.int32)
             if self._rule in _engine.PROB_RULES:
-                kwargs["probs"] = up("semantic_prob", np.float32)
+                tens["probs"] = up("semantic_prob", np.float32)
             else:
-                kwargs["semantic"] = up("semantic", np.int32)
-                kwargs["semantic_unc"] = up("semantic_unc", np.float32)
-                kwargs["semantic_max_prob"] = up("semantic_max_prob", np.float32)
+                tens["semantic"] = up("semantic", np.int32)
+                tens["semantic_unc"] = up("semantic_unc", np.float32)
+                tens["semantic_max_prob"] = up("semantic_max_prob", np.float32)
                 if self._rule == "stubborn" or self.collect_nb_data:
-                    kwargs["probs"] = up("semantic_prob", np.float32)
+                    tens["probs"] = up("semantic_prob", np.float32)
         else:
-            kwargs["semantic"] = up("semantic", np.int32)
-        eng.step(d_depth, obs["agent_position_and_rotation"], obs["camera_position_and_rotation"],
-                 [goal_id], **kwargs)
-        found, status, n_upd = eng.results()
+            tens["semantic"] = up("semantic", np.int32)
+        return tens, goal_id
+
+    def _after_step(self, eng, obs, d_depth, found, status, n_upd, goal_id):
+        """Host side of one frame after the engine stepped env `self._e`: depth written back, status,
+        naive-Bayes rows, found cells, the new cells of the trail.  Returns (is_found, whether the
+        trail has to be painted)."""
+        depth = obs["depth"]
         # the reference zeroes the sentinels in the caller's array (mapper.py:282-283)
         if isinstance(depth, torch.Tensor):
             if depth.data_ptr() != d_depth.data_ptr():
-                depth.copy_(d_depth[0])
+                depth.copy_(d_depth)
         else:
-            depth[...] = d_depth[0].cpu().numpy()
+            depth[...] = d_depth.cpu().numpy()
         self._host_cache = {}
-        self.last_status, self.last_n_updates = int(status[0]), int(n_upd[0])
-        if status[0] & 1:
+        self.last_status, self.last_n_updates = int(status), int(n_upd)
+        if status & 1:
             raise IndexError("index out of bounds for the semantic map (cell index below -dim)")
         if self.collect_nb_data and self.probablistic_mapping and self._rule in ("argmax", "stubborn"):
             self._collect_nb_rows(eng, goal_id)
         lower = self.map_bounds[:3]
         robot_pos_px = self.world2map(np.asarray(obs["agent_position_and_rotation"])[:3], lower)
-        is_found = True if found[0] else None
+        is_found = True if found else None
         if is_found:
             self.found_idx = self._disk_indices(robot_pos_px)
         # path overlay, after the found decision (mapper.py:822-839)
+        paint = False
         if self.prev_pos_px is not None:
             before = self.path_mask.astype(bool)
             self.path_mask = _draw_line(self.path_mask, (self.prev_pos_px[1], self.prev_pos_px[0]),
                                         (robot_pos_px[1], robot_pos_px[0]), 1, self.path_width_px)
             new = np.flatnonzero(self.path_mask.astype(bool) & ~before)
             if new.size:
-                eng.path_append(0, new)
-            eng.path_paint()
+                eng.path_append(self._e, new)
+            paint = True
         self.prev_pos_px = robot_pos_px
+        return is_found, paint
+
+    def update_map(self, obs: Dict[str, np.ndarray], auxillary_angle=None):
+        h, w = obs["depth"].shape
+        eng = self._ensure_engine(h, w)
+        self._sync_params(eng)
+        tens, goal_id = self._inputs(obs, eng.device)
+        kwargs = {k: (None if t is None else t.unsqueeze(0).contiguous()) for k, t in tens.items()}
+        d_depth = kwargs.pop("depth")
+        eng.step(d_depth, obs["agent_position_and_rotation"], obs["camera_position_and_rotation"],
+                 [goal_id], **kwargs)
+        found, status, n_upd = eng.results()
+        is_found, paint = self._after_step(eng, obs, d_depth[0], found[0], status[0], n_upd[0], goal_id)
+        if paint:
+            eng.path_paint()
         small, large, unc_s, unc_l = eng.ego_maps(np.asarray(obs["agent_position_and_rotation"])[None], [goal_id],
                                                   None if auxillary_angle is None else np.asarray(auxillary_angle)[None])
         ego = (small[0].cpu().numpy(), large[0].cpu().numpy(),
@@ -403,8 +421,8 @@ class SemanticMapper:
         """Feature rows of this frame's update cells for fitting the naive-Bayes models
         (mapper.py:470-500): one [k, 4] float64 array of the cells whose ground truth is the goal;
         the other cells' rows only when no update cell is a goal cell."""
-        pix, cells = eng.update_list(0, self.last_n_updates)     # ascending pixel order, like valid_flat_idx
-        maps = eng.maps[0]
+        pix, cells = eng.update_list(self._e, self.last_n_updates)     # ascending pixel order, like valid_flat_idx
+        maps = eng.maps[self._e]
         idx = torch.from_numpy(cells).to(eng.device)
         cols = [maps[name].reshape(-1)[idx].cpu().numpy() for name in
                 ("total_view", "cumulative_conf", "max_conf", "max_other_conf")]
@@ -470,7 +488,7 @@ class SemanticMapper:
     def _host(self, name):
         if self._engine is None or not getattr(self, "_bound", False):
             return None
-        maps = self._engine.maps[0]
+        maps = self._engine.maps[self._e]
         if name not in maps:
             return None
         if name not in self._host_cache:

@@ -29,7 +29,7 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(c.Config) == 9 * 4 + 2 * 4 + 4 + 4 * 8      # 9 ints, 2 floats, pad, 4 doubles
     assert ctypes.sizeof(c.EnvMaps) == 8 + 3 * 8 + 15 * 8
     assert ctypes.sizeof(c.Params) == 7 * 4 + 4 + 2 * 8 + 2 * 4
-    assert ctypes.sizeof(c.Frames) == 11 * 8
+    assert ctypes.sizeof(c.Frames) == 12 * 8
 
 
 def test_engine_refuses_to_run_without_gpu():

@@ -876,6 +876,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;
         if (sh.frame.err) atomicOr(&hdr->status, sh.frame.err);
     }
+    // A frame that raises numpy's IndexError writes nothing (the reference raises at its first
+    // indexed statement, mapper.py:338, before any map is touched): no update list, so the rule,
+    // hit/view and found kernels leave the env as it is.
+    if (sh.frame.err & SSMAP_ENV_INDEX_ERROR) return;
     const int32_t box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
     const bool may_wrap = write_list && (sh.frame.spill || pre.rmin < 0 || pre.cmin < 0);
     if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)

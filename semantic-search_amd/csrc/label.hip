@@ -107,8 +107,8 @@ __global__ void k_hv_revert(View v) {
     const int prev = v.cur_overlay ^ 1;
     const unsigned n = v.overlay_count[prev][e];
     const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
-    if (v.poses[e].skip) {
-        // no frame for this env: its map keeps last frame's overlay, and the list moves on to the
+    if (v.poses[e].skip || (v.hdr[e].status & SSMAP_ENV_INDEX_ERROR)) {
+        // no frame for this env (or one that raised IndexError): its map keeps last frame's overlay, and the list moves on to the
         // buffer the next step will undo
         int32_t *keep = v.overlay[v.cur_overlay] + (int64_t)e * v.N;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keep[i] = list[i];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
     const int e = blockIdx.y;
     const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
     const PoseBlock pb = v.poses[e];
-    if (pb.skip) return;   // no frame for this env: no decision, no rejection side effects
+    if (pb.skip || (v.hdr[e].status & SSMAP_ENV_INDEX_ERROR)) return;   // no frame for this env, or one that raised: no decision, no rejection side effects
     const int goal = pb.goal_id;
     const int R = v.disk_radius, side = 2 * R + 1;
     const int C = v.C;

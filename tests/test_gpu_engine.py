@@ -683,6 +683,8 @@ def test_index_below_minus_dim_is_reported_like_numpy():
         ref.update(scenes.make_obs(frame, agent, cam))
     with pytest.raises(IndexError):
         m.update_map(obs, None)
+    # the reference raises at its first indexed statement, before any map is written
+    assert not m.semantic_map.any() and not m.semantic_map_color.any() and np.isneginf(m.height_map).all()
 
 
 def test_frame_without_any_valid_depth_updates_nothing():

@@ -340,7 +340,9 @@ def main():
         except OSError:
             pass
         mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
-        dom_name = f"k_stream_reg<{C}, {mode}>"
+        # third template argument: how the pooled goal confidence is staged (0: every goal pools one
+        # class, as the 40-class table does; 2: the SegFormer lists, known at compile time)
+        dom_name = f"k_stream_reg<{C}, {mode}, {2 if C == 150 else 0}>"
         names = ("geometry", "winners", "stream_stage1", "rule_update", "found")
         line = {
             "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",

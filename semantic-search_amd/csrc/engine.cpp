@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -125,9 +126,12 @@ size_t carve_step_scratch(const ssmap_config &c, View &v, unsigned char *base) {
     take(v.rec_h, n_rec);
     take(v.rec_w, n_rec);
     take(v.rec_s, packed ? 0 : n_rec);
-    take(v.target, prob_rule ? EN : 0);
-    take(v.wflag, prob_rule ? EN : 0);
-    take(v.wprob, prob_rule ? EN * (size_t)c.n_classes : 0);
+    const bool direct = prob_rule && v.direct_update;
+    take(v.target, prob_rule && !direct ? EN : 0);
+    take(v.wflag, prob_rule && !direct ? EN : 0);
+    take(v.wprob, prob_rule && !direct ? EN * (size_t)c.n_classes : 0);
+    take(v.ocell, direct ? EN : 0);
+    take(v.ohnew, direct ? EN : 0);
     take(v.winners, EN * 2);
     take(v.wheight, EN);
     const size_t local = c.rule == SSMAP_RULE_GOAL_DECAY ? E * 4 * (size_t)c.max_map_h * c.max_map_w : 0;
@@ -287,6 +291,12 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
     v.wprob_stride = v.C;   // padding the rows (to 16 bytes, to whole cache lines) measured slower
+    // Narrow class counts: the streaming kernel updates the owners' map cells itself (its waves
+    // have the wave slots to wait one more memory round trip); wide rows go through staged rows
+    // and the update kernel.
+    v.direct_update = (prob_rule && (v.C == 8 || v.C == 40) && (int64_t)v.C * v.N * 4 < (1ll << 31) &&
+                       c.n_schema + 3 <= 64) ? 1 : 0;   // the register streaming kernel's narrow class counts
+    if (const char *x = getenv("SSMAP_DIRECT")) v.direct_update = v.direct_update && atoi(x) != 0;
     v.local_stride = 4ll * c.max_map_h * c.max_map_w;
     eng->step_bytes = carve_step_scratch(c, v, nullptr);
     TRY_ALLOC(dev_alloc(&eng->d_step, eng->step_bytes));
@@ -818,7 +828,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
     if (prob_rule) {
         launch_stream(lv, *f, true, nullptr, stream);
         MARK(3);
-        launch_update_prob(lv, *f, stream);
+        if (!lv.direct_update) launch_update_prob(lv, *f, stream);
     } else {
         if (f->logits) launch_stream(lv, *f, false, goal_stats ? eng->d_nb_probs : nullptr, stream);
         MARK(3);

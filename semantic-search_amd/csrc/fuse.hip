@@ -58,6 +58,90 @@ struct StreamArgs {
     const int32_t *gt;
 };
 
+// ---------------------------------------------------------------- one map cell
+// Rule update of one map cell by one 16-lane row: lane `sub` owns the classes V*(sub+16k) ..
+// +V-1 (k < K); p = this frame's probabilities, mv = the cell's fused row (updated in place and
+// written back to mrow).  Rows without a live cell (`on` false) still take part in the
+// row-local DPP steps.  Out: argmax class, and for the average family the new weight and the
+// normalised entropy of the fused row.
+// MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
+template <int MODE, int V, int K, typename VecF>
+__device__ __forceinline__ void update_row(const View &v, int C, float log_c, bool on, int sub, float *mrow,
+                                           const VecF (&p)[K], VecF (&mv)[K], float w_old,
+                                           int &bi, float &wn, float &ent_out) {
+    // every product and sum rounds on its own, as numpy's array statements do (mapper.py:540-548):
+    // with unit weights the fused average then equals the reference's bit for bit
+#pragma clang fp contract(off)
+    float best = -INFINITY;
+    bi = 0x7FFFFFFF;
+    ent_out = 0.0f;
+    wn = 0.0f;
+    if (MODE == 1) {
+        float wgt = 1.0f;
+        if (v.rule != SSMAP_RULE_AVG_PROB) {
+            float sp = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int j = 0; j < V; ++j) sp += p[k][j];
+            sp = row_sum(sp);
+            float hs = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int j = 0; j < V; ++j) hs += (on && V * (sub + 16 * k) < C) ? entr(p[k][j] / sp) : 0.0f;
+            const float ent = row_sum(hs) / log_c;
+            wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
+        }
+        wn = w_old + wgt;
+        const float rcp = 1.0f / wn;
+        float sm = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = V * (sub + 16 * k);
+            if (on && c < C) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = rcp * (p[k][j] - mv[k][j]);
+                    mv[k][j] = mv[k][j] + d * wgt;
+                    sm += mv[k][j];
+                }
+                *reinterpret_cast<VecF *>(mrow + c) = mv[k];
+            }
+        }
+        sm = row_sum(sm);
+        float hs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = V * (sub + 16 * k);
+            if (on && c < C) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    hs += entr(mv[k][j] / sm);
+                    { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
+                }
+            }
+        }
+        ent_out = row_sum(hs) / log_c;
+    } else {
+        // class 0 of the observation, broadcast over the row (the other lanes add zeros)
+        const float p0 = row_sum(sub == 0 ? p[0][0] : 0.0f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = V * (sub + 16 * k);
+            if (on && c < C) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    mv[k][j] = mv[k][j] + logf(p[k][j] / p0);
+                    { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
+                }
+                *reinterpret_cast<VecF *>(mrow + c) = mv[k];
+            }
+        }
+    }
+    row_argmax(best, bi);
+}
+
 // Classes that the goal lists of the reference's SegFormer wrapper name (infer.py:278-292: chair 19,
 // 30, 75; bed 7; plant 17; toilet 65; tv_monitor 143, 130, 141, 89; sofa 23), as a bit per class.
 __host__ __device__ constexpr uint32_t ade_pool_word(int w) {
@@ -68,6 +152,190 @@ __host__ __device__ constexpr uint32_t ade_pool_word(int w) {
 }
 constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
     ade_pool_word(0), ade_pool_word(1), ade_pool_word(2), ade_pool_word(3), ade_pool_word(4), 0, 0, 0};
+
+// ---------------------------------------------------------------- direct update (narrow rows)
+// The streaming kernel updates the map cells its pixels own by itself: no probability rows leave
+// the kernel and no update kernel runs.  Per wave:
+//   request  as soon as the per-pixel cell words are there (the class planes are still in flight):
+//            the owners' cells are exchanged through LDS, then every 16-lane row asks for one
+//            owner's map row (a vector per lane) and its scalars (height, weight, ground truth,
+//            new height; lanes 0..3 of the row), for the first kDirectPre owners of the wave;
+//   update   after the softmax: the owners park their probabilities in the wave's LDS rows, every
+//            16-lane row updates its cell exactly as k_update_prob does (update_row) and writes the
+//            map row and the cell's scalars.  Owners beyond kDirectPre (rare) follow in further
+//            passes that load at that point.
+// All of it is local to the wave (no block barrier).  The streaming kernel runs as fast at half
+// its occupancy, so the longer life of its waves (a second memory round trip) costs nothing.
+constexpr int kDirectPre = 32;   // owners per block (and pass) whose map rows are requested ahead
+struct DirectShared {
+    int count[kRegTile / 64];
+    int cell[kDirectPre];
+    int thread[kDirectPre];
+};
+template <int CT>
+struct DirectRows {
+    // one class per lane and step (16 lanes x K steps): 40 classes are 3 elements a lane where
+    // float4 units would be 4 (of which 10 lanes in 16 hold data).  The owners of the whole block
+    // are pooled: batches of four cells are dealt to the block's waves in turn, so that the rows of
+    // a batch are full (a typical block of 256 pixels owns 14 cells: four batches, one per wave,
+    // where the waves on their own would run five or six)
+    static constexpr int V = 1, K = (CT + 15) / 16, NB = kDirectPre / 4 / (kRegTile / 64);
+    typedef float VecF __attribute__((ext_vector_type(1)));
+    typedef float Vec4 __attribute__((ext_vector_type(4)));
+    VecF mv[NB][K];
+    int side[NB], cell[NB], othread[NB];
+    bool on[NB];
+    int n_blk, brank;     // owners in the block; this lane's number among them (if it owns a cell)
+    bool owner;
+    float *m_prob, *m_height, *m_weight, *m_unc;
+    uint32_t *m_gt, *m_sem;
+    uint8_t *m_color;
+    const int32_t *gt;
+    const float *hnew;
+    int pix0;
+
+    // row r of the pass = batch r / 4; batch j goes to wave j % 4 as its (j / 4)-th
+    __device__ __forceinline__ int my_row(int t, int b) const {
+        return 4 * ((t >> 6) + (kRegTile / 64) * b) + ((t & 63) >> 4);
+    }
+    // the owners r0 .. r0 + kDirectPre - 1 of the block leave their cell and thread in LDS, every
+    // 16-lane row picks up the owner it will work on (block barriers inside)
+    __device__ __forceinline__ void exchange(DirectShared &sh, int t, int cellw, int r0) {
+        if (owner && brank >= r0 && brank < r0 + kDirectPre) {
+            sh.cell[brank - r0] = cellw;
+            sh.thread[brank - r0] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int r = my_row(t, b);
+            on[b] = r0 + r < n_blk;
+            cell[b] = on[b] ? sh.cell[r] : 0;
+            othread[b] = on[b] ? sh.thread[r] : 0;
+        }
+        __syncthreads();
+    }
+    // every lane loads, from a safe address where it has nothing to do (cell 0, class 0, first pixel)
+    __device__ __forceinline__ void load(int t, bool avg) {
+        const int sub = t & 15;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float *mrow = m_prob + (int64_t)cell[b] * CT;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int c = V * (sub + 16 * k);
+                mv[b][k] = *reinterpret_cast<const VecF *>(mrow + (c < CT ? c : 0));
+            }
+            const int opix = pix0 + othread[b];
+            const int *sp = reinterpret_cast<const int *>(m_height + cell[b]);
+            if (sub == 1 && avg) sp = reinterpret_cast<const int *>(m_weight + cell[b]);
+            if (sub == 2 && gt) sp = gt + opix;
+            if (sub == 3) sp = reinterpret_cast<const int *>(hnew + opix);
+            side[b] = *sp;
+        }
+    }
+    __device__ __forceinline__ void request(DirectShared &sh, const View &v, int e, int t, int cellw,
+                                            const int32_t *gt_frame, const float *hnew_frame, int block_pix0, bool avg) {
+        // the env's map pointers once, in registers (read through the struct they would be fetched
+        // again after every store, which could alias it)
+        const ssmap_env_maps &mp = v.envs[e].maps;
+        m_prob = mp.prob_map; m_height = mp.height_map; m_weight = mp.weight_map; m_unc = mp.unc_map;
+        m_gt = mp.gt_map; m_sem = mp.semantic_map; m_color = mp.semantic_map_color;
+        gt = gt_frame; hnew = hnew_frame; pix0 = block_pix0;
+        s_cellw = cellw;
+        owner = cellw >= 0;
+        const unsigned long long owners = __ballot(owner);
+        const int wave = t >> 6, lane = t & 63;
+        if (lane == 0) sh.count[wave] = __popcll(owners);
+        __syncthreads();
+        int base = 0;
+        n_blk = 0;
+#pragma unroll
+        for (int w = 0; w < kRegTile / 64; ++w) {
+            const int c = sh.count[w];
+            base += w < wave ? c : 0;
+            n_blk += c;
+        }
+        brank = base + __popcll(owners & ((1ull << lane) - 1ull));
+        exchange(sh, t, cellw, 0);
+        load(t, avg);
+    }
+    template <int UMODE>
+    __device__ __forceinline__ void update(DirectShared &sh, const View &v, int t, const float (&x)[CT],
+                                           const int (&lut_reg)[(CT + 63) / 64], int pal_reg, bool have_gt) {
+        __shared__ __attribute__((aligned(16))) float s_rows[kDirectPre][CT];
+        if (n_blk == 0) return;   // the same for the whole block
+        const int lane = t & 63, sub = lane & 15;
+        const float log_c = logf((float)CT);
+        for (int r0 = 0; r0 < n_blk; r0 += kDirectPre) {
+            if (r0 > 0) {   // rare: more owners in the block than were requested ahead
+                exchange(sh, t, s_cellw, r0);
+                load(t, UMODE == 1);
+            }
+            if (owner && brank >= r0 && brank < r0 + kDirectPre) {
+                float *row = s_rows[brank - r0];
+#pragma unroll
+                for (int q = 0; q < CT / 4; ++q)
+                    *reinterpret_cast<Vec4 *>(row + 4 * q) = Vec4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int r = my_row(t, b);
+                if (r0 + (r & ~3) >= n_blk) break;   // wave-uniform: no cell in this batch
+                VecF p[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int c = V * (sub + 16 * k);
+                    p[k] = *reinterpret_cast<const VecF *>(&s_rows[on[b] ? r : 0][c < CT ? c : 0]);
+                    const bool used = on[b] && c < CT;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        p[k][j] = used ? p[k][j] : 0.0f;
+                        mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
+                    }
+                }
+                // the cell's scalars sit in lanes 0..3 of the row
+                const int rowbase = lane & 48;
+                const float h_old = __builtin_bit_cast(float, __shfl(side[b], rowbase));
+                const float w_old = (UMODE == 1 && on[b]) ? __builtin_bit_cast(float, __shfl(side[b], rowbase + 1)) : 0.0f;
+                const int gtv = __shfl(side[b], rowbase + 2);
+                const float hcand = __builtin_bit_cast(float, __shfl(side[b], rowbase + 3));
+                float *mrow = m_prob + (int64_t)cell[b] * CT;
+                int bi;
+                float wn, ent_out;
+                update_row<UMODE, V, K>(v, CT, log_c, on[b], sub, mrow, p, mv[b], w_old, bi, wn, ent_out);
+                // height map and ground-truth map (mapper.py:338-341, 361-363), label, colour
+                int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
+#pragma unroll
+                for (int k = 1; k < (CT + 63) / 64; ++k) {
+                    const int other = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[k]);
+                    sid = (bi >> 6) == k ? other : sid;
+                }
+                const float hnew_v = fmaxf(h_old, hcand);
+                const int id = occupancy_override(sid, hnew_v, v.use_height, v.n_schema);
+                const int rgb = __builtin_amdgcn_ds_bpermute((id & 63) << 2, pal_reg);
+                // the cell's scalars leave through two store instructions per batch: lanes 0..4 of the
+                // row write one 32-bit map each, lanes 5..7 the colour bytes (after the row reductions
+                // every lane of the row holds the same values)
+                if (on[b]) {
+                    const int cl = cell[b];
+                    int *dst = nullptr;
+                    int val = 0;
+                    if (sub == 0) { dst = reinterpret_cast<int *>(m_height + cl); val = __builtin_bit_cast(int, hnew_v); }
+                    if (sub == 1 && UMODE == 1) { dst = reinterpret_cast<int *>(m_weight + cl); val = __builtin_bit_cast(int, wn); }
+                    if (sub == 2 && UMODE == 1) { dst = reinterpret_cast<int *>(m_unc + cl); val = __builtin_bit_cast(int, ent_out); }
+                    if (sub == 3 && have_gt) { dst = reinterpret_cast<int *>(m_gt + cl); val = gtv; }
+                    if (sub == 4) { dst = reinterpret_cast<int *>(m_sem + cl); val = id; }
+                    if (dst) *dst = val;
+                    if (sub >= 5 && sub <= 7) m_color[3ll * cl + (sub - 5)] = (uint8_t)(rgb >> (8 * (sub - 5)));
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int s_cellw;   // the lane's cell word, kept for the passes beyond the first
+};
 
 // ---------------------------------------------------------------- register kernel
 // One pixel per thread.  The C class planes of the env's frame are read through one buffer
@@ -92,28 +360,55 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     // the class -> schema table, spread over the lanes (lane l holds entries l, l + 64, ...): asked
     // for in front of the class planes and looked up with a lane permute at the end, so that no
     // wave ends on a dependent gather through the saturated memory pipeline
+    constexpr bool DIRECT = MODE >= 3;            // the owners' map cells are updated here (modes 3, 4)
+    constexpr int UMODE = DIRECT ? MODE - 2 : MODE;   // 1: average family, 2: log-odds
     constexpr int kLutRegs = (CT + 63) / 64;
     int lut_reg[kLutRegs];
-    if (a.from_logits) {
+    if (a.from_logits || DIRECT) {
 #pragma unroll
         for (int k = 0; k < kLutRegs; ++k) {
             const int idx = (t & 63) + 64 * k;
             lut_reg[k] = v.lut[idx < CT ? idx : 0];
         }
     }
+    // DIRECT: the map cell this pixel owns (-1: none) and, like the class table, the colour table
+    // spread over the lanes; both asked for in front of the class planes, so that the owners'
+    // map rows can be requested while the planes are still on their way
+    int cellw = -1, pal_reg = 0;
+    if (DIRECT) {
+        const __amdgpu_buffer_rsrc_t cells = __builtin_amdgcn_make_buffer_rsrc(v.ocell + fbase, 0, v.N * 4, 0x00020000);
+        cellw = __builtin_amdgcn_raw_buffer_load_b32(cells, active ? boff : -1, 0, 2 /* nt */);
+        // (an env without a frame in this batch keeps last step's cell words: it owns nothing now)
+        if (!active || v.poses[e].skip) cellw = -1;
+        const int row = (t & 63) < v.palette_rows ? (t & 63) : 0;
+        const uint8_t *rgb = v.palette + 3 * row;
+        pal_reg = (int)rgb[0] | ((int)rgb[1] << 8) | ((int)rgb[2] << 16);
+    }
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
         x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+    DirectRows<DIRECT ? CT : 4> dr;
+    __shared__ DirectShared dsh;
+    if constexpr (DIRECT) dr.request(dsh, v, e, t, cellw, a.gt ? a.gt + fbase : nullptr, v.ohnew + fbase, blockIdx.x * kRegTile, UMODE == 1);
     // one byte per pixel says whether it owns a map cell this step; asked for after the class
     // planes (the branch below waits for it at once, and a wave that waited for it before its C
     // loads were in flight would lose a whole memory round trip).  Only the few owners then fetch
     // their list slot.  (Reading the slot word of every pixel, to have no dependent load at all,
     // measured the same: the extra 4 bytes per pixel cost what the shorter chain saves.)
     uint8_t owns = 0;
-    if (MODE != 0 && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
+    if (MODE != 0 && !DIRECT && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
+    // The owners' list slots come through a buffer load that every lane issues: the other lanes
+    // ask for an offset beyond the buffer, which returns zero without touching memory.  No
+    // branch, so the wave does not sit out this second round trip before its arithmetic (a load
+    // inside a divergent branch is waited for where the branch ends).
     int slot = -1;
-    if (MODE != 0 && owns) slot = v.target[fbase + pix];
+    if (MODE != 0 && !DIRECT) {
+        const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc(
+            v.target + fbase, 0, v.N * 4, 0x00020000);
+        const int got = __builtin_amdgcn_raw_buffer_load_b32(slots, owns ? boff : -1, 0, 0);
+        slot = owns ? got : -1;
+    }
 
     if (a.from_logits) {
         // no implicit fused multiply-add in here: the roundings are those of the reference's
@@ -191,6 +486,10 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         }
     }
     if (MODE == 0) return;
+    if constexpr (DIRECT) {
+        dr.template update<UMODE>(dsh, v, t, x, lut_reg, pal_reg, a.gt != nullptr);
+        return;
+    }
 
     // The owners' rows leave the wave through LDS: the few owner lanes (3 to 4 of 64 on a typical
     // frame) park their C probabilities in the wave's staging rows, then consecutive lanes write
@@ -417,76 +716,10 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                // rows without a live cell still take part in the (row-local) DPP steps
                 float *mrow = m_prob + (int64_t)cell[b] * C;
-                const bool on = live[b];
-                float best = -INFINITY;
-                int bi = 0x7FFFFFFF;
-                float ent_out = 0.0f, wn = 0.0f;
-                if (MODE == 1) {
-                    float wgt = 1.0f;
-                    if (v.rule != SSMAP_RULE_AVG_PROB) {
-                        float sp = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < K; ++k)
-#pragma unroll
-                            for (int j = 0; j < V; ++j) sp += p[b][k][j];
-                        sp = row_sum(sp);
-                        float hs = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < K; ++k)
-#pragma unroll
-                            for (int j = 0; j < V; ++j) hs += (on && V * (sub + 16 * k) < C) ? entr(p[b][k][j] / sp) : 0.0f;
-                        const float ent = row_sum(hs) / log_c;
-                        wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
-                    }
-                    wn = w_old[b] + wgt;
-                    const float rcp = 1.0f / wn;
-                    float sm = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int c = V * (sub + 16 * k);
-                        if (on && c < C) {
-#pragma unroll
-                            for (int j = 0; j < V; ++j) {
-                                const float d = rcp * (p[b][k][j] - mv[b][k][j]);
-                                mv[b][k][j] = mv[b][k][j] + d * wgt;
-                                sm += mv[b][k][j];
-                            }
-                            *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];
-                        }
-                    }
-                    sm = row_sum(sm);
-                    float hs = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int c = V * (sub + 16 * k);
-                        if (on && c < C) {
-#pragma unroll
-                            for (int j = 0; j < V; ++j) {
-                                hs += entr(mv[b][k][j] / sm);
-                                { const bool take = arg_better(mv[b][k][j], c + j, best, bi); best = take ? mv[b][k][j] : best; bi = take ? c + j : bi; }
-                            }
-                        }
-                    }
-                    ent_out = row_sum(hs) / log_c;
-                } else {
-                    // class 0 of the observation, broadcast over the row (the other lanes add zeros)
-                    const float p0 = row_sum(sub == 0 ? p[b][0][0] : 0.0f);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int c = V * (sub + 16 * k);
-                        if (on && c < C) {
-#pragma unroll
-                            for (int j = 0; j < V; ++j) {
-                                mv[b][k][j] = mv[b][k][j] + logf(p[b][k][j] / p0);
-                                { const bool take = arg_better(mv[b][k][j], c + j, best, bi); best = take ? mv[b][k][j] : best; bi = take ? c + j : bi; }
-                            }
-                            *reinterpret_cast<VecF *>(mrow + c) = mv[b][k];
-                        }
-                    }
-                }
-                row_argmax(best, bi);
+                int bi;
+                float wn, ent_out;
+                update_row<MODE, V, K>(v, C, log_c, live[b], sub, mrow, p[b], mv[b], w_old[b], bi, wn, ent_out);
                 if (sub == 0) {
                     const unsigned j = 16 * wave + 4 * (b0 + b) + row;
                     s_bi[j] = bi;
@@ -524,7 +757,11 @@ static void launch_reg_pool(int mode, hipStream_t s, const View &v, const Stream
     const size_t lds = POOL ? (size_t)(v.pool_slots > 0 ? v.pool_slots : 1) * kRegTile * sizeof(float) : 0;
     if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, POOL>), grid, dim3(kRegTile), lds, s, v, a);
-    else hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+    else if constexpr (CT % 4 == 0 && CT <= 64) {   // direct update of the owners' map cells (narrow rows)
+        if (mode == 3) hipLaunchKernelGGL((k_stream_reg<CT, 3, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+        else hipLaunchKernelGGL((k_stream_reg<CT, 4, POOL>), grid, dim3(kRegTile), lds, s, v, a);
+    }
 }
 template <int CT>
 static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
@@ -566,7 +803,7 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
     a.probs_out = probs_out;
     a.gt = f.semantic_gt;
     int mode = 0;
-    if (fuse) mode = v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1;
+    if (fuse) mode = (v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1) + (v.direct_update ? 2 : 0);
     // the register kernels address a whole frame with 32-bit buffer offsets
     if ((int64_t)v.C * v.N * 4 < (1ll << 31)) {
         switch (v.C) {

@@ -344,7 +344,15 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
             }
         }
         if (QUAD && dirty) *reinterpret_cast<float4 *>(depth_all + fbase + i0) = make_float4(d[0], d[1], d[2], d[3]);
-        if (write_target) {
+        if (write_target == 2) {   // direct update: no pixel owns a cell yet
+            if (QUAD) {
+                *reinterpret_cast<int4 *>(v.ocell + fbase + i0) = make_int4(-1, -1, -1, -1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k < v.N) v.ocell[fbase + i0 + k] = -1;
+            }
+        } else if (write_target) {
             if (QUAD) {
                 *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
             } else {
@@ -496,7 +504,7 @@ struct WinnerPre {
     int rmin, rmax, cmin, cmax;      // predicted box (frame header)
     int Hm, Wm;
     double lower_x, lower_z;
-    double cam_x, cam_y, cam_z, h_cut;
+    double cam_x, cam_y, cam_z, h_cut, agent_y;
     unsigned cnt;                    // bin_cnt of geometry block wave + 16 lane for table blockIdx.x
 };
 
@@ -775,7 +783,10 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             if (write_list) {
                 const unsigned pos = s_base + s_cnt[it * kWaves + wave] +
                                      (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull));
-                if (write_target) { v.target[fbase + pix] = (int)pos; v.wflag[fbase + pix] = 1; }
+                if (write_target == 2) {
+                    v.ocell[fbase + pix] = cell;
+                    v.ohnew[fbase + pix] = (float)(unorder_f64(table_h[s]) - pre.agent_y);
+                } else if (write_target) { v.target[fbase + pix] = (int)pos; v.wflag[fbase + pix] = 1; }
                 int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
                 const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
                 *out = make_int2((int)word, cell);
@@ -836,7 +847,8 @@ __device__ inline void resolve_wrapped(const View &v, int e, unsigned n, int wri
         const int owner = max(max(qs.x, qs.y), max(qs.z, qs.w));
         if (owner != pix + 1) {
             list[i].x = (int)((uint32_t)pc.x | kLostBit);
-            if (write_target) v.wflag[fbase + pix] = 0;
+            if (write_target == 2) v.ocell[fbase + pix] = -1;
+            else if (write_target) v.wflag[fbase + pix] = 0;
         }
     }
 }
@@ -865,6 +877,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         pre.lower_x = mp.lower[0]; pre.lower_z = mp.lower[2];
         pre.cam_x = pb.trans[0]; pre.cam_y = pb.trans[1]; pre.cam_z = pb.trans[2];
         pre.h_cut = pb.h_cut;
+        pre.agent_y = pb.agent[1];
         const int b = (int)(threadIdx.x >> 6) + (kWinnerThreads / 64) * (int)(threadIdx.x & 63);
         pre.cnt = (v.geom_blocks <= kMaxGeomBlocksBinned && b < v.geom_blocks)
                       ? v.bin_cnt[((int64_t)e * kMaxParts + blockIdx.x) * v.geom_blocks + b] : 0u;
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
-    const int wt = prob_rule ? 1 : 0;
+    const int wt = prob_rule ? (v.direct_update ? 2 : 1) : 0;
     dim3 grid((v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock, v.E);
     PosePack pack;
     if (host_poses) memcpy(pack.p, host_poses, sizeof(PoseBlock) * v.E);   // at most kPosePack envs
@@ -924,7 +937,7 @@ void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, prob_rule ? 1 : 0, 1);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1);
 }
 
 }  // namespace ssmap

@@ -114,6 +114,9 @@ struct View {
     int32_t rec_packed;
     int32_t *target;           // [E][N] slot in the frame's update list, valid where wflag is set
     uint8_t *wflag;            // [E][N] 1 = this pixel owns a map cell this step (cleared by the geometry kernel)
+    int32_t *ocell;            // [E][N] direct update (see direct_update): map cell a pixel owns this step, -1 = none
+    float *ohnew;              // [E][N] ... and its height above the agent, as the height map takes it (owners only)
+    int32_t direct_update;     // the streaming kernel updates the owners' map cells itself (no staged rows, no update kernel)
     float *wprob;              // [E][N][wprob_stride] class probabilities of the update pixels, row = list slot
     int32_t wprob_stride;      // floats per row (>= C)
     int32_t *winners;          // [E][N][2] update list: (pixel word, cell) pairs in cell order per table

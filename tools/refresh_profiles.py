@@ -27,6 +27,11 @@ def main(tag):
     fetch = glob.glob(os.path.join(SRC, "fetch", "**", "*counter_collection.csv"), recursive=True)[0]
     write = glob.glob(os.path.join(SRC, "write", "**", "*counter_collection.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(DST, f"{tag}_bench_log_odds_c40_E16_kernel_stats.csv"))
+    for other in glob.glob(os.path.join(SRC, "stats_*")):   # tools/refresh_workload_profiles.sh
+        if os.path.isdir(other):
+            found = glob.glob(os.path.join(other, "**", "*kernel_stats.csv"), recursive=True)
+            if found:
+                shutil.copy(found[0], os.path.join(DST, f"{tag}_bench_{os.path.basename(other)[6:]}_E16_kernel_stats.csv"))
     shutil.copy(fetch, os.path.join(DST, f"{tag}_pmc_fetch_size_counter_collection.csv"))
     shutil.copy(write, os.path.join(DST, f"{tag}_pmc_write_size_counter_collection.csv"))
     f, w = per_kernel(fetch), per_kernel(write)
@@ -34,7 +39,7 @@ def main(tag):
     for k in sorted(f):
         kernels[k] = {"fetch_size_kib": round(f[k], 1), "write_size_kib": round(w.get(k, 0.0), 1),
                       "hbm_bytes_per_launch": round((2 * f[k] + w.get(k, 0.0)) * 1024)}
-    stream = next(k for k in kernels if k.startswith("k_stream_reg<40, 2"))
+    stream = next(k for k in kernels if k.startswith("k_stream_reg<40,"))
     out = {
         "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `python3 bench.py --steps 4 "
                 "--warmup 1 --no-cpu-baseline` (profiles/%s_pmc_*_counter_collection.csv), mean per dispatch; "

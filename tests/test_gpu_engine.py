@@ -836,3 +836,50 @@ def test_one_env_of_a_batch_is_reset_while_the_others_go_on(rule):
     big.close()
     for s in singles:
         s.close()
+
+
+@pytest.mark.parametrize("rule,c", [("height_map_log_odds", 40), ("height_map_w2_avg_prob", 40), ("height_map_avg_prob", 8)])
+def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
+    """The two homes of the probability rules' update for 8 and 40 classes: inside the streaming kernel
+    (default) and as staged rows + k_update_prob (SSMAP_DIRECT=0 when the engine is created).  Same
+    update_row; integer maps and the log-odds sums are bit-identical, the averages and their entropy
+    weights agree to 1e-6 (the entropy sums run over another class-to-lane layout)."""
+    import semantic_search_amd as ssa
+    lut = scenes.schema_lut(c) if c == 40 else scenes.small_lut(c)
+    bounds = np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5])
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate=rule, seg_model_n_classes=c, max_map_hw=ssa.map_size(bounds, 0.03))
+    engs = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("SSMAP_DIRECT", direct)
+        eng = ssa.MapEngine(2, (96, 128), **kw)
+        eng.set_schema(lut)
+        for e in range(2):
+            eng.reset_env(e, bounds)
+        engs.append(eng)
+    rng = np.random.default_rng(11)
+    for t in range(4):
+        frames, ag, cam = [], [], []
+        for e in range(2):
+            a, cm = scenes.make_pose(1.2 + 0.3 * e, 0.0, 1.0 + 0.3 * t, np.pi + 0.75 + 0.1 * e)
+            frames.append(scenes.room_frame(rng, 96, 128, c, 1.0, cm, lut=lut, box=(2.0, 2.0, 2.9, 2.8, 0.5), sharp=4.0))
+            ag.append(a)
+            cam.append(cm)
+        dev = lambda key, dt: torch.from_numpy(np.stack([f[key] for f in frames]).astype(dt)).cuda()
+        res = []
+        for eng in engs:
+            eng.step(dev("depth", np.float32), np.stack(ag), np.stack(cam), [3, 3],
+                     probs=dev("semantic_prob", np.float32), semantic_gt=dev("semantic_gt", np.int32))
+            res.append(eng.results())
+        for x, y in zip(*res):
+            assert np.array_equal(x, y), t
+        assert res[0][2].min() > 100
+    for e in range(2):
+        for nm, m in engs[0].maps[e].items():
+            other = engs[1].maps[e][nm]
+            if m.dtype.is_floating_point and "log_odds" not in rule and nm in ("avg_prob_seg_map", "avg_prob_weight_map", "unc_map"):
+                assert torch.allclose(m, other, rtol=1e-6, atol=1e-7, equal_nan=True), nm
+            else:
+                assert torch.equal(m, other), nm
+    for eng in engs:
+        eng.close()

@@ -128,7 +128,6 @@ size_t carve_step_scratch(const ssmap_config &c, View &v, unsigned char *base) {
     take(v.rec_s, packed ? 0 : n_rec);
     const bool direct = prob_rule && v.direct_update;
     take(v.target, prob_rule && !direct ? EN : 0);
-    take(v.wflag, prob_rule && !direct ? EN : 0);
     take(v.wprob, prob_rule && !direct ? EN * (size_t)c.n_classes : 0);
     take(v.ocell, direct ? EN : 0);
     take(v.ohnew, direct ? EN : 0);
@@ -291,11 +290,10 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
     v.wprob_stride = v.C;   // padding the rows (to 16 bytes, to whole cache lines) measured slower
-    // Narrow class counts: the streaming kernel updates the owners' map cells itself (its waves
-    // have the wave slots to wait one more memory round trip); wide rows go through staged rows
-    // and the update kernel.
-    v.direct_update = (prob_rule && (v.C == 8 || v.C == 40) && (int64_t)v.C * v.N * 4 < (1ll << 31) &&
-                       c.n_schema + 3 <= 64) ? 1 : 0;   // the register streaming kernel's narrow class counts
+    // Class counts with a direct variant of the register streaming kernel: it updates the owners'
+    // map cells itself; the others go through staged rows and the update kernel.
+    v.direct_update = (prob_rule && direct_class_count(v.C) && (int64_t)v.C * v.N * 4 < (1ll << 31) &&
+                       c.n_schema + 3 <= 64) ? 1 : 0;
     if (const char *x = getenv("SSMAP_DIRECT")) v.direct_update = v.direct_update && atoi(x) != 0;
     v.local_stride = 4ll * c.max_map_h * c.max_map_w;
     eng->step_bytes = carve_step_scratch(c, v, nullptr);

@@ -6,8 +6,8 @@
 // (lane <-> pixel, so one wave-load reads 256 contiguous bytes of one class plane) and kept
 //   * in registers when C is one of the compiled sizes (kernel k_stream_reg), or
 //   * in a private LDS column of stride 257 floats otherwise (kernel k_stream_lds).
-// Pixels that own a map cell this step (wflag[pix] set by the winner kernel, target[pix] = their
-// slot in the frame's update list) write their probability vector to row `slot` of a compact
+// Pixels that own a map cell this step (target[pix] = their slot in the frame's update list, set by
+// the winner kernel; -1 for the others) write their probability vector to row `slot` of a compact
 // [K][C] buffer (vector stores under the owners' execution mask; staging the rows through LDS
 // for fully coalesced writes measured the same); the streaming pass never waits on map memory.
 // k_update_prob then gives every update cell to a 16-lane row of a wave, lanes over the classes:
@@ -24,11 +24,13 @@ constexpr int kRegTile = 256;      // block of the register kernel (64 and 1024 
 constexpr int kStride = kTile + 1;
 constexpr int kStageRows = 8;      // owner rows a wave of the register kernel stages per pass
 
-// scipy.special.entr: -x log x, 0 at 0, -inf below 0.  The full-precision logarithm: the kernel
-// that calls it waits on scattered memory, not on the vector unit.
-__device__ inline float entr(float x) {
-    if (x > 0.0f) return -x * logf(x);
-    return x == 0.0f ? 0.0f : (x != x ? x : -INFINITY);
+// One term of an entropy sum in bits: -x log2(x) with the hardware logarithm (v_log_f32, one ulp),
+// 0 at 0, -inf below 0, NaN for NaN (scipy.special.entr).  A denormal x counts as 0: its term is
+// below 1e-35 and the hardware logarithm does not take denormals.  With the accurate logf and a
+// division per class the update of 150-class rows was bound by the vector unit, not by memory.
+__device__ inline float entr_bits(float x) {
+    const float t = -x * __builtin_amdgcn_logf(x);
+    return x >= 1.17549435e-38f ? t : (x >= 0.0f ? 0.0f : (x != x ? x : -INFINITY));
 }
 
 __device__ inline int occupancy_override(int id, float h, int use_height, int n_schema) {
@@ -66,7 +68,7 @@ struct StreamArgs {
 // normalised entropy of the fused row.
 // MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
 template <int MODE, int V, int K, typename VecF>
-__device__ __forceinline__ void update_row(const View &v, int C, float log_c, bool on, int sub, float *mrow,
+__device__ __forceinline__ void update_row(const View &v, int C, float log2_c, bool on, int sub, float *mrow,
                                            const VecF (&p)[K], VecF (&mv)[K], float w_old,
                                            int &bi, float &wn, float &ent_out) {
     // every product and sum rounds on its own, as numpy's array statements do (mapper.py:540-548):
@@ -85,12 +87,13 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log_c, bo
 #pragma unroll
                 for (int j = 0; j < V; ++j) sp += p[k][j];
             sp = row_sum(sp);
+            const float rsp = 1.0f / sp;     // one division per row: p * rsp is within an ulp of p / sp
             float hs = 0.0f;
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
-                for (int j = 0; j < V; ++j) hs += (on && V * (sub + 16 * k) < C) ? entr(p[k][j] / sp) : 0.0f;
-            const float ent = row_sum(hs) / log_c;
+                for (int j = 0; j < V; ++j) hs += (on && V * (sub + 16 * k) < C) ? entr_bits(p[k][j] * rsp) : 0.0f;
+            const float ent = row_sum(hs) / log2_c;
             wgt = v.rule == SSMAP_RULE_W_AVG_PROB ? 1.0f - ent : 1.0f / ent;
         }
         wn = w_old + wgt;
@@ -110,6 +113,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log_c, bo
             }
         }
         sm = row_sum(sm);
+        const float rsm = 1.0f / sm;
         float hs = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -117,12 +121,12 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log_c, bo
             if (on && c < C) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    hs += entr(mv[k][j] / sm);
+                    hs += entr_bits(mv[k][j] * rsm);
                     { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
                 }
             }
         }
-        ent_out = row_sum(hs) / log_c;
+        ent_out = row_sum(hs) / log2_c;
     } else {
         // class 0 of the observation, broadcast over the row (the other lanes add zeros)
         const float p0 = row_sum(sub == 0 ? p[0][0] : 0.0f);
@@ -153,6 +157,60 @@ __host__ __device__ constexpr uint32_t ade_pool_word(int w) {
 constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
     ade_pool_word(0), ade_pool_word(1), ade_pool_word(2), ade_pool_word(3), ade_pool_word(4), 0, 0, 0};
 
+// The env's maps as the direct update writes them: the pointers once, in registers (read through
+// the struct they would be fetched again after every store, which could alias it).
+struct DirectMaps {
+    float *prob, *height, *weight, *unc;
+    uint32_t *gt, *sem;
+    uint8_t *color;
+    __device__ __forceinline__ void take(const ssmap_env_maps &mp) {
+        prob = mp.prob_map; height = mp.height_map; weight = mp.weight_map; unc = mp.unc_map;
+        gt = mp.gt_map; sem = mp.semantic_map; color = mp.semantic_map_color;
+    }
+};
+
+// One 16-lane row finishes its cell: p = the owner pixel's probabilities, mv = the cell's fused
+// row (lane `sub` holds the classes sub + 16k), side = the cell's scalars in lanes 0..3 of the row
+// (old height, old weight, ground truth of the owner pixel, the owner pixel's height).  update_row,
+// then height map and ground-truth map (mapper.py:338-341, 361-363), label, colour.
+template <int UMODE, int CT, int K, typename VecF>
+__device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, float log2_c, bool on, int lane, int cell,
+                                            int side, const VecF (&p)[K], VecF (&mv)[K],
+                                            const int (&lut_reg)[(CT + 63) / 64], int pal_reg, bool have_gt) {
+    const int sub = lane & 15, rowbase = lane & 48;
+    const float h_old = __builtin_bit_cast(float, __shfl(side, rowbase));
+    const float w_old = (UMODE == 1 && on) ? __builtin_bit_cast(float, __shfl(side, rowbase + 1)) : 0.0f;
+    const int gtv = __shfl(side, rowbase + 2);
+    const float hcand = __builtin_bit_cast(float, __shfl(side, rowbase + 3));
+    float *mrow = m.prob + (int64_t)cell * CT;
+    int bi;
+    float wn, ent_out;
+    update_row<UMODE, 1, K>(v, CT, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
+    int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
+#pragma unroll
+    for (int k = 1; k < (CT + 63) / 64; ++k) {
+        const int other = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[k]);
+        sid = (bi >> 6) == k ? other : sid;
+    }
+    const float hnew_v = fmaxf(h_old, hcand);
+    const int id = occupancy_override(sid, hnew_v, v.use_height, v.n_schema);
+    const int rgb = __builtin_amdgcn_ds_bpermute((id & 63) << 2, pal_reg);
+    // the cell's scalars leave through two store instructions: lanes 0..4 of the row write one
+    // 32-bit map each, lanes 5..7 the colour bytes (after the row reductions every lane of the
+    // row holds the same values)
+    if (on) {
+        int *dst = nullptr;
+        int val = 0;
+        if (sub == 0) { dst = reinterpret_cast<int *>(m.height + cell); val = __builtin_bit_cast(int, hnew_v); }
+        if (sub == 1 && UMODE == 1) { dst = reinterpret_cast<int *>(m.weight + cell); val = __builtin_bit_cast(int, wn); }
+        if (sub == 2 && UMODE == 1) { dst = reinterpret_cast<int *>(m.unc + cell); val = __builtin_bit_cast(int, ent_out); }
+        if (sub == 3 && have_gt) { dst = reinterpret_cast<int *>(m.gt + cell); val = gtv; }
+        if (sub == 4) { dst = reinterpret_cast<int *>(m.sem + cell); val = id; }
+        if (dst) *dst = val;
+        if (sub >= 5 && sub <= 7) m.color[3ll * cell + (sub - 5)] = (uint8_t)(rgb >> (8 * (sub - 5)));
+    }
+}
+
 // ---------------------------------------------------------------- direct update (narrow rows)
 // The streaming kernel updates the map cells its pixels own by itself: no probability rows leave
 // the kernel and no update kernel runs.  Per wave:
@@ -180,16 +238,15 @@ struct DirectRows {
     // a batch are full (a typical block of 256 pixels owns 14 cells: four batches, one per wave,
     // where the waves on their own would run five or six)
     static constexpr int V = 1, K = (CT + 15) / 16, NB = kDirectPre / 4 / (kRegTile / 64);
+    static constexpr int SV = CT % 4 == 0 ? 4 : (CT % 2 == 0 ? 2 : 1);   // widest vector an owner parks its row with
     typedef float VecF __attribute__((ext_vector_type(1)));
-    typedef float Vec4 __attribute__((ext_vector_type(4)));
+    typedef float VecS __attribute__((ext_vector_type(SV)));
     VecF mv[NB][K];
     int side[NB], cell[NB], othread[NB];
     bool on[NB];
     int n_blk, brank;     // owners in the block; this lane's number among them (if it owns a cell)
     bool owner;
-    float *m_prob, *m_height, *m_weight, *m_unc;
-    uint32_t *m_gt, *m_sem;
-    uint8_t *m_color;
+    DirectMaps maps;
     const int32_t *gt;
     const float *hnew;
     int pix0;
@@ -216,19 +273,25 @@ struct DirectRows {
         __syncthreads();
     }
     // every lane loads, from a safe address where it has nothing to do (cell 0, class 0, first pixel)
-    __device__ __forceinline__ void load(int t, bool avg) {
+    __device__ __forceinline__ void load_rows(int t) {
         const int sub = t & 15;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float *mrow = m_prob + (int64_t)cell[b] * CT;
+            const float *mrow = maps.prob + (int64_t)cell[b] * CT;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int c = V * (sub + 16 * k);
                 mv[b][k] = *reinterpret_cast<const VecF *>(mrow + (c < CT ? c : 0));
             }
+        }
+    }
+    __device__ __forceinline__ void load_side(int t, bool avg) {
+        const int sub = t & 15;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
             const int opix = pix0 + othread[b];
-            const int *sp = reinterpret_cast<const int *>(m_height + cell[b]);
-            if (sub == 1 && avg) sp = reinterpret_cast<const int *>(m_weight + cell[b]);
+            const int *sp = reinterpret_cast<const int *>(maps.height + cell[b]);
+            if (sub == 1 && avg) sp = reinterpret_cast<const int *>(maps.weight + cell[b]);
             if (sub == 2 && gt) sp = gt + opix;
             if (sub == 3) sp = reinterpret_cast<const int *>(hnew + opix);
             side[b] = *sp;
@@ -238,9 +301,7 @@ struct DirectRows {
                                             const int32_t *gt_frame, const float *hnew_frame, int block_pix0, bool avg) {
         // the env's map pointers once, in registers (read through the struct they would be fetched
         // again after every store, which could alias it)
-        const ssmap_env_maps &mp = v.envs[e].maps;
-        m_prob = mp.prob_map; m_height = mp.height_map; m_weight = mp.weight_map; m_unc = mp.unc_map;
-        m_gt = mp.gt_map; m_sem = mp.semantic_map; m_color = mp.semantic_map_color;
+        maps.take(v.envs[e].maps);
         gt = gt_frame; hnew = hnew_frame; pix0 = block_pix0;
         s_cellw = cellw;
         owner = cellw >= 0;
@@ -258,7 +319,8 @@ struct DirectRows {
         }
         brank = base + __popcll(owners & ((1ull << lane) - 1ull));
         exchange(sh, t, cellw, 0);
-        load(t, avg);
+        load_side(t, avg);
+        load_rows(t);
     }
     template <int UMODE>
     __device__ __forceinline__ void update(DirectShared &sh, const View &v, int t, const float (&x)[CT],
@@ -266,17 +328,22 @@ struct DirectRows {
         __shared__ __attribute__((aligned(16))) float s_rows[kDirectPre][CT];
         if (n_blk == 0) return;   // the same for the whole block
         const int lane = t & 63, sub = lane & 15;
-        const float log_c = logf((float)CT);
+        const float log2_c = log2f((float)CT);
         for (int r0 = 0; r0 < n_blk; r0 += kDirectPre) {
             if (r0 > 0) {   // rare: more owners in the block than were requested ahead
                 exchange(sh, t, s_cellw, r0);
-                load(t, UMODE == 1);
+                load_side(t, UMODE == 1);
+                load_rows(t);
             }
             if (owner && brank >= r0 && brank < r0 + kDirectPre) {
                 float *row = s_rows[brank - r0];
 #pragma unroll
-                for (int q = 0; q < CT / 4; ++q)
-                    *reinterpret_cast<Vec4 *>(row + 4 * q) = Vec4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                for (int q = 0; q < CT / SV; ++q) {
+                    VecS val;
+#pragma unroll
+                    for (int j = 0; j < SV; ++j) val[j] = x[SV * q + j];
+                    *reinterpret_cast<VecS *>(row + SV * q) = val;
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -295,41 +362,7 @@ struct DirectRows {
                         mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
                     }
                 }
-                // the cell's scalars sit in lanes 0..3 of the row
-                const int rowbase = lane & 48;
-                const float h_old = __builtin_bit_cast(float, __shfl(side[b], rowbase));
-                const float w_old = (UMODE == 1 && on[b]) ? __builtin_bit_cast(float, __shfl(side[b], rowbase + 1)) : 0.0f;
-                const int gtv = __shfl(side[b], rowbase + 2);
-                const float hcand = __builtin_bit_cast(float, __shfl(side[b], rowbase + 3));
-                float *mrow = m_prob + (int64_t)cell[b] * CT;
-                int bi;
-                float wn, ent_out;
-                update_row<UMODE, V, K>(v, CT, log_c, on[b], sub, mrow, p, mv[b], w_old, bi, wn, ent_out);
-                // height map and ground-truth map (mapper.py:338-341, 361-363), label, colour
-                int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
-#pragma unroll
-                for (int k = 1; k < (CT + 63) / 64; ++k) {
-                    const int other = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[k]);
-                    sid = (bi >> 6) == k ? other : sid;
-                }
-                const float hnew_v = fmaxf(h_old, hcand);
-                const int id = occupancy_override(sid, hnew_v, v.use_height, v.n_schema);
-                const int rgb = __builtin_amdgcn_ds_bpermute((id & 63) << 2, pal_reg);
-                // the cell's scalars leave through two store instructions per batch: lanes 0..4 of the
-                // row write one 32-bit map each, lanes 5..7 the colour bytes (after the row reductions
-                // every lane of the row holds the same values)
-                if (on[b]) {
-                    const int cl = cell[b];
-                    int *dst = nullptr;
-                    int val = 0;
-                    if (sub == 0) { dst = reinterpret_cast<int *>(m_height + cl); val = __builtin_bit_cast(int, hnew_v); }
-                    if (sub == 1 && UMODE == 1) { dst = reinterpret_cast<int *>(m_weight + cl); val = __builtin_bit_cast(int, wn); }
-                    if (sub == 2 && UMODE == 1) { dst = reinterpret_cast<int *>(m_unc + cl); val = __builtin_bit_cast(int, ent_out); }
-                    if (sub == 3 && have_gt) { dst = reinterpret_cast<int *>(m_gt + cl); val = gtv; }
-                    if (sub == 4) { dst = reinterpret_cast<int *>(m_sem + cl); val = id; }
-                    if (dst) *dst = val;
-                    if (sub >= 5 && sub <= 7) m_color[3ll * cl + (sub - 5)] = (uint8_t)(rgb >> (8 * (sub - 5)));
-                }
+                direct_cell<UMODE, CT, K>(v, maps, log2_c, on[b], lane, cell[b], side[b], p, mv[b], lut_reg, pal_reg, have_gt);
             }
             __syncthreads();
         }
@@ -384,6 +417,17 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         const uint8_t *rgb = v.palette + 3 * row;
         pal_reg = (int)rgb[0] | ((int)rgb[1] << 8) | ((int)rgb[2] << 16);
     }
+    // staged rows: the pixel's slot in the frame's update list (-1: it owns no cell), asked for in
+    // front of the class planes like the cell word, so that no wave waits for a second memory round
+    // trip behind its C loads (at two waves per SIMD, 150 classes, that wait is a sixth of the
+    // wave's life)
+    int slot = -1;
+    if (MODE != 0 && !DIRECT) {
+        const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc(v.target + fbase, 0, v.N * 4, 0x00020000);
+        slot = __builtin_amdgcn_raw_buffer_load_b32(slots, active ? boff : -1, 0, 2 /* nt */);
+        // (an env without a frame in this batch keeps last step's slots: it stages nothing now)
+        if (!active || v.poses[e].skip) slot = -1;
+    }
     float x[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -391,25 +435,6 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     DirectRows<DIRECT ? CT : 4> dr;
     __shared__ DirectShared dsh;
     if constexpr (DIRECT) dr.request(dsh, v, e, t, cellw, a.gt ? a.gt + fbase : nullptr, v.ohnew + fbase, blockIdx.x * kRegTile, UMODE == 1);
-    // one byte per pixel says whether it owns a map cell this step; asked for after the class
-    // planes (the branch below waits for it at once, and a wave that waited for it before its C
-    // loads were in flight would lose a whole memory round trip).  Only the few owners then fetch
-    // their list slot.  (Reading the slot word of every pixel, to have no dependent load at all,
-    // measured the same: the extra 4 bytes per pixel cost what the shorter chain saves.)
-    uint8_t owns = 0;
-    if (MODE != 0 && !DIRECT && active) owns = __builtin_nontemporal_load(v.wflag + fbase + pix);
-    // The owners' list slots come through a buffer load that every lane issues: the other lanes
-    // ask for an offset beyond the buffer, which returns zero without touching memory.  No
-    // branch, so the wave does not sit out this second round trip before its arithmetic (a load
-    // inside a divergent branch is waited for where the branch ends).
-    int slot = -1;
-    if (MODE != 0 && !DIRECT) {
-        const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc(
-            v.target + fbase, 0, v.N * 4, 0x00020000);
-        const int got = __builtin_amdgcn_raw_buffer_load_b32(slots, owns ? boff : -1, 0, 0);
-        slot = owns ? got : -1;
-    }
-
     if (a.from_logits) {
         // no implicit fused multiply-add in here: the roundings are those of the reference's
         // y = x / T, y - max(y)
@@ -615,7 +640,7 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
         }
     }
     if (MODE == 0) return;
-    const int slot = (active && v.wflag[fbase + pix]) ? v.target[fbase + pix] : -1;
+    const int slot = (active && !v.poses[e].skip) ? v.target[fbase + pix] : -1;
     if (slot >= 0) {
         float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
         for (int c = 0; c < C; ++c) dst[c] = col[c * kStride];
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     // with unit weights the fused average then equals the reference's bit for bit
 #pragma clang fp contract(off)
     typedef float VecF __attribute__((ext_vector_type(V)));
-    constexpr int NB = V * K <= 4 ? 4 : 2;   // row-batches in flight per wave (of the 4 a pass needs)
+    constexpr int NB = V * K <= 4 ? 4 : 2;   // row-batches in flight per wave (of the 4 a pass needs; all four of wide rows measured slower)
     constexpr unsigned kRun = 64;     // list slots per block pass
     __shared__ int s_bi[kRun];
     __shared__ float s_wn[kRun], s_ent[kRun];
@@ -656,7 +681,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     uint8_t *const m_color = mp_ref.semantic_map_color;
     const double agent_y = v.poses[e].agent[1];
     const int C = v.C;
-    const float log_c = logf((float)C);
+    const float log2_c = log2f((float)C);
     const int lane = threadIdx.x & 63, sub = lane & 15, row = lane >> 4;
     const unsigned wave = threadIdx.x >> 6;
     for (unsigned r0 = blockIdx.x * kRun; r0 < n; r0 += gridDim.x * kRun) {
@@ -719,7 +744,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                 float *mrow = m_prob + (int64_t)cell[b] * C;
                 int bi;
                 float wn, ent_out;
-                update_row<MODE, V, K>(v, C, log_c, live[b], sub, mrow, p[b], mv[b], w_old[b], bi, wn, ent_out);
+                update_row<MODE, V, K>(v, C, log2_c, live[b], sub, mrow, p[b], mv[b], w_old[b], bi, wn, ent_out);
                 if (sub == 0) {
                     const unsigned j = 16 * wave + 4 * (b0 + b) + row;
                     s_bi[j] = bi;
@@ -758,7 +783,7 @@ static void launch_reg_pool(int mode, hipStream_t s, const View &v, const Stream
     if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 2) hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);
-    else if constexpr (CT % 4 == 0 && CT <= 64) {   // direct update of the owners' map cells (narrow rows)
+    else if constexpr (direct_class_count(CT)) {   // direct update of the owners' map cells
         if (mode == 3) hipLaunchKernelGGL((k_stream_reg<CT, 3, POOL>), grid, dim3(kRegTile), lds, s, v, a);
         else hipLaunchKernelGGL((k_stream_reg<CT, 4, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     }

@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
                 for (int k = 0; k < 4; ++k)
                     if (i0 + k < v.N) v.ocell[fbase + i0 + k] = -1;
             }
-        } else if (write_target) {
+        } else if (write_target) {   // staged rows: no pixel has a slot in the update list yet
             if (QUAD) {
-                *reinterpret_cast<uint32_t *>(v.wflag + fbase + i0) = 0u;   // four pixels' flags
+                *reinterpret_cast<int4 *>(v.target + fbase + i0) = make_int4(-1, -1, -1, -1);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (i0 + k < v.N) v.wflag[fbase + i0 + k] = 0;
+                    if (i0 + k < v.N) v.target[fbase + i0 + k] = -1;
             }
         }
         // at most kGeomPixPerBlock live pixels in a block: the place is inside the block's share.
@@ -786,7 +786,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
                 if (write_target == 2) {
                     v.ocell[fbase + pix] = cell;
                     v.ohnew[fbase + pix] = (float)(unorder_f64(table_h[s]) - pre.agent_y);
-                } else if (write_target) { v.target[fbase + pix] = (int)pos; v.wflag[fbase + pix] = 1; }
+                } else if (write_target) { v.target[fbase + pix] = (int)pos; }
                 int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
                 const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
                 *out = make_int2((int)word, cell);
@@ -848,7 +848,7 @@ __device__ inline void resolve_wrapped(const View &v, int e, unsigned n, int wri
         if (owner != pix + 1) {
             list[i].x = (int)((uint32_t)pc.x | kLostBit);
             if (write_target == 2) v.ocell[fbase + pix] = -1;
-            else if (write_target) v.wflag[fbase + pix] = 0;
+            else if (write_target) v.target[fbase + pix] = -1;
         }
     }
 }

@@ -90,6 +90,12 @@ struct EnvState {
     uint32_t bound;
 };
 
+// Class counts for which the register streaming kernel has a variant that updates the owners' map
+// cells itself (the EMSANet NYUv2 head and the 8 classes of the tests).  At 150 classes the kernel
+// runs at two waves per SIMD with its vector unit as busy as its memory pipeline: the update inside
+// it measured slower than staged rows and the update kernel.
+constexpr bool direct_class_count(int c) { return c == 8 || c == 40; }
+
 // Everything a kernel needs, passed by value.
 struct View {
     int32_t E, H, W, N, C, n_schema, rule, use_height;
@@ -112,8 +118,7 @@ struct View {
                                //        2^kPackPixBits pixels (rec_packed), else the pixel
     uint32_t *rec_s;           // same shape: slot (only when !rec_packed)
     int32_t rec_packed;
-    int32_t *target;           // [E][N] slot in the frame's update list, valid where wflag is set
-    uint8_t *wflag;            // [E][N] 1 = this pixel owns a map cell this step (cleared by the geometry kernel)
+    int32_t *target;           // [E][N] staged rows: the pixel's slot in the frame's update list, -1 = it owns no cell (cleared by the geometry kernel)
     int32_t *ocell;            // [E][N] direct update (see direct_update): map cell a pixel owns this step, -1 = none
     float *ohnew;              // [E][N] ... and its height above the agent, as the height map takes it (owners only)
     int32_t direct_update;     // the streaming kernel updates the owners' map cells itself (no staged rows, no update kernel)

@@ -845,7 +845,7 @@ def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
     update_row; integer maps and the log-odds sums are bit-identical, the averages and their entropy
     weights agree to 1e-6 (the entropy sums run over another class-to-lane layout)."""
     import semantic_search_amd as ssa
-    lut = scenes.schema_lut(c) if c == 40 else scenes.small_lut(c)
+    lut = scenes.schema_lut(c) if c >= 40 else scenes.small_lut(c)
     bounds = np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5])
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate=rule, seg_model_n_classes=c, max_map_hw=ssa.map_size(bounds, 0.03))

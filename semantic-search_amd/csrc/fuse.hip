@@ -270,7 +270,7 @@ struct DirectRows {
             cell[b] = on[b] ? sh.cell[r] : 0;
             othread[b] = on[b] ? sh.thread[r] : 0;
         }
-        __syncthreads();
+        // (the slots are written again only by a later pass, behind the barriers of this pass's update)
     }
     // every lane loads, from a safe address where it has nothing to do (cell 0, class 0, first pixel)
     __device__ __forceinline__ void load_rows(int t) {
@@ -364,7 +364,7 @@ struct DirectRows {
                 }
                 direct_cell<UMODE, CT, K>(v, maps, log2_c, on[b], lane, cell[b], side[b], p, mv[b], lut_reg, pal_reg, have_gt);
             }
-            __syncthreads();
+            if (r0 + kDirectPre < n_blk) __syncthreads();   // another pass reuses the LDS rows (the same for the whole block)
         }
     }
     int s_cellw;   // the lane's cell word, kept for the passes beyond the first

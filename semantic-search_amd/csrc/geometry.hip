@@ -96,15 +96,14 @@ struct PixelGeom {
     bool invalid;               // depth <= 0 after sentinel zeroing
 };
 
-// depth -> world point -> map cell and height (mapper.py:18-32, 305-311, 851-863, 319-329);
-// dk is the depth after sentinel zeroing, (u, yr) = (column, row - H/2).  FAST uses the verified
-// reciprocal forms above and reports through `sure` whether every step was proven exact.
+// depth -> world point -> floored map coordinates (mapper.py:18-32, 305-311, 851-863); dk is the
+// depth after sentinel zeroing, (u, yr) = (column, row - H/2).  An invalid depth (ok false) sits at
+// the camera position.  FAST uses the verified reciprocal forms above and reports through `sure`
+// whether every step was proven exact.
 template <bool FAST>
-__device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
-                                                float dk, int u, double yr, bool &sure) {
-    PixelGeom g;
-    const int Hm = mp.map_h, Wm = mp.map_w;
-    const bool ok = dk > 0.0f;
+__device__ inline void pixel_world(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp, float dk, int u,
+                                   double yr, bool &sure, bool &ok, double &wy, double &fr, double &fc) {
+    ok = dk > 0.0f;
     double x = 0.0, y = 0.0, z = 0.0;
     if (ok) {
         z = (double)dk;
@@ -113,10 +112,31 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
         y = FAST ? div_known(ay, v.fy, v.inv_fy, v.inv_fy_wide, sure) : ay / v.fy;
     }
     const double wx = __builtin_fma(pb.rot[2], z, __builtin_fma(pb.rot[1], y, pb.rot[0] * x)) + pb.trans[0];
-    const double wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
+    wy = __builtin_fma(pb.rot[5], z, __builtin_fma(pb.rot[4], y, pb.rot[3] * x)) + pb.trans[1];
     const double wz = __builtin_fma(pb.rot[8], z, __builtin_fma(pb.rot[7], y, pb.rot[6] * x)) + pb.trans[2];
-    const double fr = FAST ? floor_div_known(wz - mp.lower[2], v.inv_p2m, sure) : floor((wz - mp.lower[2]) / v.p2m);
-    const double fc = FAST ? floor_div_known(wx - mp.lower[0], v.inv_p2m, sure) : floor((wx - mp.lower[0]) / v.p2m);
+    fr = FAST ? floor_div_known(wz - mp.lower[2], v.inv_p2m, sure) : floor((wz - mp.lower[2]) / v.p2m);
+    fc = FAST ? floor_div_known(wx - mp.lower[0], v.inv_p2m, sure) : floor((wx - mp.lower[0]) / v.p2m);
+}
+
+// The masks of mapper.py:326-338 on floored coordinates, in double so that huge or non-finite
+// coordinates never reach a cast.  numpy casts the floored coordinate to int64 (mapper.py:863), and
+// the x86 conversion turns a NaN, an infinity and any value beyond the int64 range into INT64_MIN:
+// such a coordinate passes the upper-bound mask and is an index far below -dim.
+__device__ inline void cell_masks(double fr, double fc, int Hm, int Wm, bool &below_upper, bool &above_lower) {
+    const bool r_min = !(fr < 9223372036854775808.0), c_min = !(fc < 9223372036854775808.0);
+    below_upper = (r_min || fr < (double)Hm) && (c_min || fc < (double)Wm);
+    above_lower = !r_min && !c_min && fr >= -(double)Hm && fc >= -(double)Wm;
+}
+
+// mapper cell and height of one pixel (mapper.py:319-329) from pixel_world.
+template <bool FAST>
+__device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &pb, const ssmap_env_maps &mp,
+                                                float dk, int u, double yr, bool &sure) {
+    PixelGeom g;
+    const int Hm = mp.map_h, Wm = mp.map_w;
+    bool ok;
+    double wy, fr, fc;
+    pixel_world<FAST>(v, pb, mp, dk, u, yr, sure, ok, wy, fr, fc);
     g.id = kDeadCell;
     g.key = 0;
     g.row = g.col = 0;
@@ -130,13 +150,8 @@ __device__ inline PixelGeom pixel_geometry_impl(const View &v, const PoseBlock &
         g.in_box = below_upper && above_lower;
         g.index_error = below_upper && !above_lower && pass;
     } else {
-    // Comparisons in double so that huge or non-finite coordinates never reach a cast.  numpy
-    // casts the floored coordinate to int64 (mapper.py:863), and the x86 conversion turns a NaN,
-    // an infinity and any value beyond the int64 range into INT64_MIN: such a coordinate passes
-    // the upper-bound mask and is an index far below -dim.
-    const bool r_min = !(fr < 9223372036854775808.0), c_min = !(fc < 9223372036854775808.0);
-    const bool below_upper = (r_min || fr < (double)Hm) && (c_min || fc < (double)Wm);
-    const bool above_lower = !r_min && !c_min && fr >= -(double)Hm && fc >= -(double)Wm;
+    bool below_upper, above_lower;
+    cell_masks(fr, fc, Hm, Wm, below_upper, above_lower);
     g.in_box = below_upper && above_lower && wy == wy;
     g.index_error = !g.in_box && below_upper && !above_lower && pass;   // index below -dim: numpy raises IndexError
     }
@@ -853,6 +868,131 @@ __device__ inline void resolve_wrapped(const View &v, int e, unsigned n, int wri
     }
 }
 
+// numpy raises IndexError for a frame only if a SELECTED pixel has an index below -dim
+// (mapper.py:331-338): the tallest pixel of its cell, over all pixels of the frame (ties to the
+// lowest pixel), that also passes the height and depth tests.  The geometry kernel reports a
+// candidate: some passing pixel lies in such a cell.  The candidate stands unless every such cell
+// holds something taller that does not pass: a pixel at or above the height cut-off (it beats every
+// passing pixel), or, in the cell of the camera, the invalid-depth pixels (they sit at the camera
+// position, mapper.py:28-31) when none of the cell's passing pixels beats them.  One block (the
+// frame's last winner block) decides, in two sweeps over the frame with the exact geometry:
+//   A  the below-range cells of the pixels at or above the cut-off go into an LDS hash set
+//      (coordinates as 32-bit codes, INT64_MIN as its own code);
+//   B  a passing pixel in a below-range cell that is not in the set (and, in the camera's cell, beats
+//      the invalid-depth pixels) confirms the error.
+// Heights that are NaN never win a cell.  What cannot be decided exactly (a coordinate beyond 32
+// bits that is not INT64_MIN, a set that does not fit) confirms the error.
+constexpr uint32_t kCodeMin = 0x80000000u;   // numpy's cast of a non-finite / out-of-range coordinate
+__device__ inline bool coord_code(double f, uint32_t &code) {
+    if (!(f < 9223372036854775808.0) || f < -9223372036854775808.0) { code = kCodeMin; return true; }
+    if (!(fabs(f) < 2147483647.0)) return false;
+    code = (uint32_t)(int32_t)f;
+    return true;
+}
+__device__ inline bool index_error_confirmed(const View &v, const float *__restrict__ depth_env, int e,
+                                             WinnerShared &sh, const WinnerPre &pre) {
+    constexpr unsigned long long kEmpty = ~0ull;   // (-1, -1) is no below-range cell
+    constexpr int kProbes = 128;
+    __shared__ unsigned int s_verdict, s_overflow;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const PoseBlock &pb = v.poses[e];
+    const int Hm = pre.Hm, Wm = pre.Wm;
+    for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) sh.table_h[s] = kEmpty;
+    if (threadIdx.x == 0) { s_verdict = 0; s_overflow = 0; }
+    __syncthreads();
+    auto slot_of = [](unsigned long long key) {
+        key *= 0x9E3779B97F4A7C15ull;
+        return (unsigned)(key >> 40) & (unsigned)(kSlots - 1);
+    };
+    // sweep A
+    for (int i = threadIdx.x; i < v.N; i += kWinnerThreads) {
+        const int r = i / v.W, c = i - r * v.W;
+        bool unused = true, ok, below_upper, above_lower;
+        double wy, fr, fc;
+        pixel_world<false>(v, pb, mp, depth_env[i], c, (double)r - (double)v.H / 2.0, unused, ok, wy, fr, fc);
+        cell_masks(fr, fc, Hm, Wm, below_upper, above_lower);
+        if (!ok || !below_upper || above_lower || !(wy == wy) || wy < pb.h_cut) continue;
+        uint32_t cr, cc;
+        if (!coord_code(fr, cr) || !coord_code(fc, cc)) continue;   // (its cell's candidates confirm the error in sweep B)
+        const unsigned long long key = ((unsigned long long)cr << 32) | cc;
+        unsigned s = slot_of(key);
+        bool placed = false;
+        for (int k = 0; k < kProbes && !placed; ++k) {
+            const unsigned long long old = atomicCAS(&sh.table_h[s], kEmpty, key);
+            placed = old == kEmpty || old == key;
+            s = (s + 1) & (unsigned)(kSlots - 1);
+        }
+        if (!placed) s_overflow = 1u;
+    }
+    __syncthreads();
+    if (s_overflow) return true;
+    // the camera's cell, where the invalid-depth pixels sit
+    bool has_cam = false;
+    unsigned long long cam_key = 0;
+    const unsigned min_inv = sh.frame.min_invalid_pixel;
+    if (min_inv != kNoPixel) {
+        const double fr = floor(((0.0 + pre.cam_z) - pre.lower_z) / v.p2m);
+        const double fc = floor(((0.0 + pre.cam_x) - pre.lower_x) / v.p2m);
+        bool below_upper, above_lower;
+        cell_masks(fr, fc, Hm, Wm, below_upper, above_lower);
+        uint32_t cr, cc;
+        if (below_upper && !above_lower && coord_code(fr, cr) && coord_code(fc, cc)) {
+            has_cam = true;
+            cam_key = ((unsigned long long)cr << 32) | cc;
+        }
+    }
+    const double cam_h = 0.0 + pre.cam_y;
+    // sweep B
+    for (int i = threadIdx.x; i < v.N; i += kWinnerThreads) {
+        const int r = i / v.W, c = i - r * v.W;
+        bool unused = true, ok, below_upper, above_lower;
+        double wy, fr, fc;
+        pixel_world<false>(v, pb, mp, depth_env[i], c, (double)r - (double)v.H / 2.0, unused, ok, wy, fr, fc);
+        cell_masks(fr, fc, Hm, Wm, below_upper, above_lower);
+        if (!ok || !below_upper || above_lower || !(wy < pb.h_cut)) continue;   // not a candidate
+        uint32_t cr, cc;
+        bool confirmed = true;
+        if (coord_code(fr, cr) && coord_code(fc, cc)) {
+            const unsigned long long key = ((unsigned long long)cr << 32) | cc;
+            unsigned s = slot_of(key);
+            bool in_set = false;
+            for (int k = 0; k < kProbes; ++k) {
+                const unsigned long long at = sh.table_h[s];
+                if (at == key) { in_set = true; break; }
+                if (at == kEmpty) break;
+                s = (s + 1) & (unsigned)(kSlots - 1);
+            }
+            if (in_set) confirmed = false;
+            else if (has_cam && key == cam_key) confirmed = wy > cam_h || (wy == cam_h && (unsigned)i < min_inv);
+        }
+        if (confirmed) s_verdict = 1u;
+    }
+    __syncthreads();
+    return s_verdict != 0u;
+}
+
+// A frame that raises writes nothing (the reference raises at its first indexed statement,
+// mapper.py:338, before any map is touched): the update list the winner blocks have emitted is
+// withdrawn, so the rule, hit/view and found kernels leave the env as it is.
+__device__ inline void withdraw_update_list(const View &v, int e, unsigned n, int write_target) {
+    const int64_t fbase = (int64_t)e * v.N;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
+    if (write_target)
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+            const int pix = (int)((uint32_t)list[i].x & kPixMask);
+            if (write_target == 2) v.ocell[fbase + pix] = -1;
+            else v.target[fbase + pix] = -1;
+        }
+    if (threadIdx.x == 0) {
+        FrameHeader *hdr = v.hdr + e;
+        hdr->n_winners = 0;
+        hdr->n_neg = 0;
+        hdr->wrmin = hdr->wcmin = 0x7FFFFFFF;
+        hdr->wrmax = hdr->wcmax = (int32_t)0x80000000;
+        atomicOr(&hdr->status, (uint32_t)SSMAP_ENV_INDEX_ERROR);
+    }
+}
+
 // Frames whose predicted cell box fits the 16 tables and holds every live pixel are read as
 // per-table record ranges; the others (spilled) are scanned pixel by pixel, once per table.
 // Only a frame whose cell box reaches below zero, or a spilled one, can hold wrapped cells: the
@@ -885,21 +1025,19 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     // clearing the tables overlaps with those loads
     for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { sh.table_h[s] = 0ull; sh.table_i[s] = kNoPixel; }
     fold_reports(rep, sh);
+    // an index-error report of the geometry kernel is a candidate: the frame's last block decides
+    const bool err_candidate = (sh.frame.err & SSMAP_ENV_INDEX_ERROR) != 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;
-        if (sh.frame.err) atomicOr(&hdr->status, sh.frame.err);
+        if (sh.frame.err & ~(uint32_t)SSMAP_ENV_INDEX_ERROR) atomicOr(&hdr->status, sh.frame.err & ~(uint32_t)SSMAP_ENV_INDEX_ERROR);
     }
-    // A frame that raises numpy's IndexError writes nothing (the reference raises at its first
-    // indexed statement, mapper.py:338, before any map is touched): no update list, so the rule,
-    // hit/view and found kernels leave the env as it is.
-    if (sh.frame.err & SSMAP_ENV_INDEX_ERROR) return;
     const int32_t box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
     const bool may_wrap = write_list && (sh.frame.spill || pre.rmin < 0 || pre.cmin < 0);
     if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)
         winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre);
     else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre);
     else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre);
-    if (!may_wrap) return;
+    if (!may_wrap && !err_candidate) return;
     __syncthreads();   // every thread's list entries and the block's header atomics are issued
     if (threadIdx.x == 0) {
         __threadfence();
@@ -908,8 +1046,13 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (__hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    resolve_wrapped(v, e, __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), write_target);
+    const unsigned n_list = __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err_candidate && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh, pre)) {
+        withdraw_update_list(v, e, write_list ? n_list : 0u, write_target);
+        return;
+    }
+    if (!may_wrap || __hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    resolve_wrapped(v, e, n_list, write_target);
 }
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {

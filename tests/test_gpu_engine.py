@@ -687,6 +687,64 @@ def test_index_below_minus_dim_is_reported_like_numpy():
     assert not m.semantic_map.any() and not m.semantic_map_color.any() and np.isneginf(m.height_map).all()
 
 
+def test_index_below_minus_dim_under_a_taller_rejected_pixel_is_no_error():
+    """numpy raises only for a SELECTED cell (mapper.py:331-338): a pixel below -dim that passes the
+    height test does not raise when a pixel above the cut-off is the tallest of its cell.  Flat depth
+    bands seen level from outside the map: every image column of a band is one cell, and the band
+    that straddles the horizon has its upper rows above the cut-off.  The engine agrees with the
+    oracle on the report, on the update set and on the maps."""
+    import semantic_search_amd as ssa
+    h, w = 48, 64
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))
+    cases = []
+    for trial in range(16):     # a 20 x 20 map seen from up to 4 m outside: candidates, some of them real errors
+        rng = np.random.default_rng(trial)
+        agent, cam = scenes.make_pose(rng.uniform(0, 4.4), 0.0, rng.uniform(0, 4.4), rng.uniform(0, 2 * np.pi), pitch=0.0)
+        depth = np.full((h, w), np.float32(rng.uniform(0.7, 4.5)))
+        if trial % 2:
+            depth[2 * h // 3:] = np.float32(rng.uniform(1.5, 4.5))
+        cases.append((np.array([4.0, 0.0, 4.0, 4.6, 2.5, 4.6]), (20, 20), agent, cam, depth, rng))
+    for k in range(7, 14):      # a 100 x 100 map: the near band below -dim under its own upper rows, the far band inside
+        rng = np.random.default_rng(100 + k)
+        agent, cam = scenes.make_pose(-3.0, 0.0, 3.5, k * np.pi / 8, pitch=0.0)
+        depth = np.full((h, w), np.float32(1.0))
+        depth[2 * h // 3:] = np.float32(4.0)
+        if k % 2:               # invalid depths sit in the camera's cell, itself below -dim here
+            depth[rng.random((h, w)) < 0.05] = np.float32(0.0)
+        cases.append((np.array([2.0, 0.0, 2.0, 5.0, 2.5, 5.0]), (100, 100), agent, cam, depth, rng))
+    suppressed = both = raised_frames = 0
+    for bounds, (mh, mw), agent, cam, depth, rng in cases:
+        frame = scenes.uniform_frame(rng, h, w, 0, 1.0)
+        frame["depth"] = depth
+        rows, cols, heights, valid = mo.project_frame(depth.copy(), 59.0, (0.5, 5.0), cam, bounds[:3], 0.03)
+        cand = valid & (heights < cam[1] + 0.1) & (rows < mh) & (cols < mw) & ((rows < -mh) | (cols < -mw))
+        ref = mo.OracleMapper(path_overlay=False, **kw)
+        ref.reset(bounds)
+        eng = ssa.MapEngine(1, (h, w), max_map_hw=(mh, mw), **kw)
+        maps = eng.reset_env(0, bounds)
+        raised = False
+        try:
+            ref.update(scenes.make_obs(frame, agent, cam))
+        except IndexError:
+            raised = True
+        eng.step(torch.from_numpy(depth[None].copy()).cuda(), agent[None], cam[None], [3],
+                 semantic=torch.from_numpy(frame["semantic"][None].astype(np.int32)).cuda())
+        found, status, n_upd = eng.results()
+        assert bool(status[0] & 1) == raised
+        if raised:
+            raised_frames += 1
+            assert n_upd[0] == 0 and np.isneginf(maps["height_map"].cpu().numpy()).all()
+        else:
+            suppressed += int(cand.any())
+            both += int(cand.any() and n_upd[0] > 0)
+            pix, _ = eng.update_list(0, int(n_upd[0]))
+            assert np.array_equal(np.sort(pix), np.sort(ref.last_update_pixels))
+            assert np.array_equal(maps["height_map"].cpu().numpy(), ref.height_map)
+            assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map)
+        eng.close()
+    assert suppressed >= 8 and both >= 3 and raised_frames >= 3, (suppressed, both, raised_frames)
+
+
 def test_frame_without_any_valid_depth_updates_nothing():
     import semantic_search_amd as ssa
     m = ssa.SemanticMapper(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0))

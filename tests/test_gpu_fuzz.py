@@ -4,8 +4,8 @@ pitch, depth sentinels, depths beyond depth_max (frames that leave the predicted
 depth images (thousands of pixels in one cell), structured and uncorrelated depth.
 
 Bar: update set, height map, ground-truth map and labels bit-exact; fused probabilities within
-rtol 1e-5 / atol 1e-6.  A scenario in which either side reports numpy's IndexError (a selected
-cell index below -dim) is only checked for that report."""
+rtol 1e-5 / atol 1e-6.  numpy's IndexError (a selected cell index below -dim) is reported by the
+engine on exactly the frames on which the oracle raises; such a scenario ends there."""
 import os
 
 import numpy as np
@@ -112,14 +112,18 @@ def test_random_scenario_matches_oracle(seed, degenerate):
                 ref.update(obs)
         except IndexError:
             raised = True
+        before = {k: t.clone() for k, t in maps.items()}
         eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
                  probs=_dev(frame["semantic_prob"][None], np.float32),
                  semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            # the engine may report the index error where numpy does not (a rejected taller pixel
-            # hides the offending one), never the other way round
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        # numpy raises only when the offending pixel is the tallest of its cell: so does the engine
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
+            # ... before its first map write (mapper.py:338): the frame leaves every map as it was
+            assert n_upd[0] == 0
+            for k, t in maps.items():
+                assert torch.equal(t.view(torch.uint8), before[k].view(torch.uint8)), f"frame {i}: {k} changed by a frame that raises"
             eng.close()
             return
         pix, _ = eng.update_list(0, int(n_upd[0]))
@@ -189,8 +193,8 @@ def test_random_scenario_label_rules(seed):
         eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
                  semantic=_dev(frame["semantic"][None], np.int32), **extra)
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
             eng.close()
             return
         assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
@@ -248,8 +252,8 @@ def test_random_scenario_hit_view_rules(seed):
                  semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
                  semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
             eng.close()
             return
         assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
@@ -305,8 +309,8 @@ def test_random_scenario_stubborn_rule(seed):
                  semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
                  semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
             eng.close()
             return
         assert np.array_equal(maps["semantic_map"].cpu().numpy().view(np.uint32), ref.semantic_map), f"frame {i}"
@@ -361,8 +365,8 @@ def test_random_rooms_goal_decay(seed):
                  semantic_max_prob=_dev(frame["semantic_max_prob"][None], np.float32),
                  semantic_gt=_dev(frame["semantic_gt"][None], np.int32))
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
             eng.close()
             return
         assert bool(found[0]) == bool(found_ref), f"frame {i}: found"
@@ -425,8 +429,8 @@ def test_random_rooms_found_decision(seed):
         eng.step(_dev(frame["depth"][None], np.float32), agent[None], cam[None], [3],
                  semantic_gt=_dev(frame["semantic_gt"][None], np.int32), **extra)
         found, status, n_upd = eng.results()
-        if raised or status[0]:
-            assert status[0] & 1, "numpy raised IndexError, the engine did not report it"
+        assert bool(status[0] & 1) == raised, f"frame {i}: numpy raised IndexError: {raised}, the engine reported: {bool(status[0] & 1)}"
+        if raised:
             eng.close()
             return
         seen.append(bool(found_ref))

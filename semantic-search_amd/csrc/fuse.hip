@@ -33,6 +33,15 @@ __device__ inline float entr_bits(float x) {
     return x >= 1.17549435e-38f ? t : (x >= 0.0f ? 0.0f : (x != x ? x : -INFINITY));
 }
 
+// Natural logarithm through the hardware base-2 logarithm (v_log_f32, one ulp), about two ulp in
+// all; a denormal argument is scaled first (the instruction does not take denormals).  log(0) =
+// -inf, log(x < 0) = NaN, NaN and +inf pass through.
+__device__ inline float log_hw(float x) {
+    const bool tiny = x < 1.17549435e-38f;
+    const float l2 = __builtin_amdgcn_logf(tiny ? x * 4294967296.0f : x) - (tiny ? 32.0f : 0.0f);
+    return l2 * 0.693147180559945309f;
+}
+
 __device__ inline int occupancy_override(int id, float h, int use_height, int n_schema) {
     if (!use_height || n_schema != 9) return id;
     if (id == 0 || id == 1 || id == 2) {
@@ -128,15 +137,20 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
         }
         ent_out = row_sum(hs) / log2_c;
     } else {
-        // class 0 of the observation, broadcast over the row (the other lanes add zeros)
+        // class 0 of the observation, broadcast over the row (the other lanes add zeros); one division
+        // per row: p * r0 is within an ulp of p / p0 and has its zeros, infinities and NaNs.  A p0
+        // so small that its reciprocal would overflow is scaled by 2^64 first, and p with it (exact).
         const float p0 = row_sum(sub == 0 ? p[0][0] : 0.0f);
+        const float sc = fabsf(p0) < 7.9e-31f ? 18446744073709551616.0f : 1.0f;
+        const float r0 = 1.0f / (p0 * sc);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = V * (sub + 16 * k);
             if (on && c < C) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    mv[k][j] = mv[k][j] + logf(p[k][j] / p0);
+                    const float q = (p[k][j] * sc) * r0;
+                    mv[k][j] = mv[k][j] + log_hw(q);
                     { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
                 }
                 *reinterpret_cast<VecF *>(mrow + c) = mv[k];

@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     if (!s_last) return;
     __threadfence();
     const unsigned n_list = __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (err_candidate && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh, pre)) {
+    if (__builtin_expect(err_candidate, 0) && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh, pre)) {
         withdraw_update_list(v, e, write_list ? n_list : 0u, write_target);
         return;
     }

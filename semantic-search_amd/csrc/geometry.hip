@@ -890,13 +890,15 @@ __device__ inline bool coord_code(double f, uint32_t &code) {
     return true;
 }
 __device__ inline bool index_error_confirmed(const View &v, const float *__restrict__ depth_env, int e,
-                                             WinnerShared &sh, const WinnerPre &pre) {
+                                             WinnerShared &sh) {
     constexpr unsigned long long kEmpty = ~0ull;   // (-1, -1) is no below-range cell
     constexpr int kProbes = 128;
     __shared__ unsigned int s_verdict, s_overflow;
+    // (everything is read again from memory here: nothing of this rare path is kept in registers
+    // across the winner selection)
     const ssmap_env_maps &mp = v.envs[e].maps;
     const PoseBlock &pb = v.poses[e];
-    const int Hm = pre.Hm, Wm = pre.Wm;
+    const int Hm = mp.map_h, Wm = mp.map_w;
     for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) sh.table_h[s] = kEmpty;
     if (threadIdx.x == 0) { s_verdict = 0; s_overflow = 0; }
     __syncthreads();
@@ -931,8 +933,8 @@ __device__ inline bool index_error_confirmed(const View &v, const float *__restr
     unsigned long long cam_key = 0;
     const unsigned min_inv = sh.frame.min_invalid_pixel;
     if (min_inv != kNoPixel) {
-        const double fr = floor(((0.0 + pre.cam_z) - pre.lower_z) / v.p2m);
-        const double fc = floor(((0.0 + pre.cam_x) - pre.lower_x) / v.p2m);
+        const double fr = floor(((0.0 + pb.trans[2]) - mp.lower[2]) / v.p2m);
+        const double fc = floor(((0.0 + pb.trans[0]) - mp.lower[0]) / v.p2m);
         bool below_upper, above_lower;
         cell_masks(fr, fc, Hm, Wm, below_upper, above_lower);
         uint32_t cr, cc;
@@ -941,7 +943,7 @@ __device__ inline bool index_error_confirmed(const View &v, const float *__restr
             cam_key = ((unsigned long long)cr << 32) | cc;
         }
     }
-    const double cam_h = 0.0 + pre.cam_y;
+    const double cam_h = 0.0 + pb.trans[1];
     // sweep B
     for (int i = threadIdx.x; i < v.N; i += kWinnerThreads) {
         const int r = i / v.W, c = i - r * v.W;
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     if (!s_last) return;
     __threadfence();
     const unsigned n_list = __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_expect(err_candidate, 0) && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh, pre)) {
+    if (__builtin_expect(err_candidate, 0) && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh)) {
         withdraw_update_list(v, e, write_list ? n_list : 0u, write_target);
         return;
     }

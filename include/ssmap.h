@@ -57,8 +57,10 @@ typedef enum ssmap_rule {
 } ssmap_rule;
 
 /* Per-env status bits reported by ssmap_read_results(). */
-#define SSMAP_ENV_INDEX_ERROR 1u   /* a cell index below -dim was selected: the reference
-                                      raises IndexError at mapper.py:338 */
+#define SSMAP_ENV_INDEX_ERROR 1u   /* a cell index below -dim was selected (the tallest pixel of
+                                      that cell passes the height and depth tests): the reference
+                                      raises IndexError at mapper.py:338, before its first map
+                                      write; the step leaves this env's maps as they were */
 
 #define SSMAP_MAX_CLASSES 256
 #define SSMAP_MAX_MAP_DIM 8192

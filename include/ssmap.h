@@ -139,7 +139,8 @@ typedef struct ssmap_frames {
                                           (its update_map was not called): its maps, pose, path and
                                           hv overlay stay as they are, its results read found 0,
                                           status 0, n_updates 0; its slices of the arrays above are
-                                          not read (its stage-1 outputs are unspecified) */
+                                          neither read nor validated (its stage-1 outputs are
+                                          unspecified) */
 } ssmap_frames;
 
 /* SemanticMapper.__init__ (mapper.py:49-191): validates the config, allocates scratch. */
@@ -178,9 +179,12 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps);
  * (mapper.py:276-821): stages 1-5 enqueued on `stream` (a hipStream_t passed as void*). */
 int ssmap_step(ssmap_engine *eng, const ssmap_frames *frames, void *stream);
 
-/* ssmap_step for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
- * Same arguments, same kernels and bit-identical results; the difference is where the per-step
+/* ssmap_step for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc, code that runs while another thread captures a HIP graph).  No
+ * counterpart in the reference.  Every step must be enqueued by a live call: the call prepares the
+ * poses on the host (they travel as kernel arguments or through a pinned ring it waits on) and
+ * flips host-side state, so a captured graph of it would replay stale poses -- it allocates
+ * nothing, it is not replayable.  Same arguments, same kernels and bit-identical results; the difference is where the per-step
  * scratch lives (pixel records, per-block counts, owner flags, update list, staged probability
  * rows, goal_decay's local maps): not in the block ssmap_create allocated but in a file-scope
  * device array of SSMAP_STATIC_SCRATCH_BYTES that every GPU loading the library holds until the
@@ -206,7 +210,8 @@ int ssmap_stage1(ssmap_engine *eng, const float *logits, float temperature,
  * cell inside the found disk around the robot cell of that step carries the goal's schema id
  * (env.py:581-593; the disk is the one the found decision uses), anywhere[e] = some gt_map cell at
  * all does (env.py:600, 604).  HOST arrays [E]; either may be NULL (its scan is then skipped).
- * Waits for `stream`. */
+ * An env that has had no frame since ssmap_bind_env (every step so far skipped it) has no robot
+ * cell and no goal yet: both answers are 0.  Waits for `stream`. */
 int ssmap_gt_goal_query(ssmap_engine *eng, int32_t *in_disk, int32_t *anywhere, void *stream);
 
 /* Waits for `stream`, then copies per-env results of the last step to HOST arrays [E]:

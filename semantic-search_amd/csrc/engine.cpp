@@ -156,6 +156,7 @@ struct ssmap_engine {
     PoseBlock *d_poses = nullptr;
     std::vector<PoseBlock> h_poses;       // this step's poses when they travel as kernel arguments
     std::vector<PoseBlock> last_poses;    // pose of every env's last frame (a skipped env keeps it)
+    std::vector<uint8_t> has_frame;       // a frame has arrived for the env since its maps were bound
     PoseBlock *h_ring[kPoseRing] = {};    // pinned staging otherwise (more than kPosePack envs)
     hipEvent_t pose_done[kPoseRing] = {};
     int ring = 0;
@@ -335,6 +336,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
 #undef TRY_ALLOC
     eng->h_poses.assign(c.n_envs, PoseBlock{});
     eng->last_poses.assign(c.n_envs, PoseBlock{});
+    eng->has_frame.assign(c.n_envs, 0);
     for (int i = 0; i < kPoseRing && c.n_envs > kPosePack; ++i) {
         if (hipHostMalloc(reinterpret_cast<void **>(&eng->h_ring[i]), sizeof(PoseBlock) * v.E) != hipSuccess ||
             hipEventCreateWithFlags(&eng->pose_done[i], hipEventDisableTiming) != hipSuccess) {
@@ -503,6 +505,9 @@ int ssmap_bind_env(ssmap_engine *eng, int32_t e, const ssmap_env_maps *maps) {
         HIP_TRY(hipMemcpy(eng->view.overlay_count[i] + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(eng->view.path_count + e, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
     eng->path_n[e] = 0;
+    // a new episode: the env has no robot cell and no goal until its first frame
+    eng->last_poses[e] = PoseBlock{};
+    eng->has_frame[e] = 0;
     return SSMAP_OK;
 }
 
@@ -746,6 +751,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
             return fail(SSMAP_ERR_NOT_READY, "the goal statistics need the class count and ssmap_set_schema (goal class lists)");
         if (!f->probs && !f->logits) return fail(SSMAP_ERR_INVALID_ARG, "semantic_prob (or logits) is required for the goal statistics");
         for (int e = 0; e < c.n_envs; ++e) {
+            if (f->skip && f->skip[e]) continue;   // no frame for this env: its slices are not read
             const int g = f->goal_sem_id[e];
             if (g < 3 || g > 8) return fail(SSMAP_ERR_INVALID_ARG, "goal id outside [3, 8]");
             if (r == SSMAP_RULE_STUBBORN && !v.prm.nb_stats && !eng->nb_set[g - 3])
@@ -767,6 +773,12 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
             v.nb_probs = eng->d_nb_probs;
         }
     }
+
+    // a refused call changes nothing: the size check of the static home comes before any pose work
+    if (static_home && eng->step_bytes > kStaticScratchBytes)
+        return fail(SSMAP_ERR_UNSUPPORTED, "ssmap_step_noalloc: this engine's per-step scratch (" +
+                    std::to_string(eng->step_bytes) + " bytes) exceeds the static array (" +
+                    std::to_string(kStaticScratchBytes) + " bytes); use ssmap_step");
 
     // ---- pose preparation on the host (a few hundred flops per env)
     const bool packed = c.n_envs <= kPosePack;
@@ -797,6 +809,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
         b.skip = 0;
         predict_box(c, mp, b);
         eng->last_poses[e] = b;
+        eng->has_frame[e] = 1;
     }
 
     if (!packed) {
@@ -806,13 +819,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
 
     // the view the kernels get: the engine's, with the per-step scratch at its home for this call
     View lv = v;
-    if (static_home) {
-        if (eng->step_bytes > kStaticScratchBytes)
-            return fail(SSMAP_ERR_UNSUPPORTED, "ssmap_step_noalloc: this engine's per-step scratch (" +
-                        std::to_string(eng->step_bytes) + " bytes) exceeds the static array (" +
-                        std::to_string(kStaticScratchBytes) + " bytes); use ssmap_step");
-        carve_step_scratch(c, lv, eng->d_static);
-    }
+    if (static_home) carve_step_scratch(c, lv, eng->d_static);
     eng->last_list = lv.winners;
     hipEvent_t *marks = nullptr;
     if (eng->prof_capacity && eng->prof_steps < eng->prof_capacity)
@@ -894,8 +901,10 @@ int ssmap_gt_goal_query(ssmap_engine *eng, int32_t *in_disk, int32_t *anywhere, 
                            hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     for (int e = 0; e < eng->cfg.n_envs; ++e) {
-        if (in_disk) in_disk[e] = eng->h_query[2 * e];
-        if (anywhere) anywhere[e] = eng->h_query[2 * e + 1];
+        // an env without a frame since its maps were bound has no robot cell and no goal yet
+        const bool live = eng->has_frame[e] != 0;
+        if (in_disk) in_disk[e] = live ? eng->h_query[2 * e] : 0;
+        if (anywhere) anywhere[e] = live ? eng->h_query[2 * e + 1] : 0;
     }
     return SSMAP_OK;
 }

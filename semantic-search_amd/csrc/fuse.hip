@@ -51,11 +51,11 @@ __device__ inline int occupancy_override(int id, float h, int use_height, int n_
     return id;
 }
 
-__device__ inline void commit_cell(const ssmap_env_maps &mp, const uint8_t *palette, int cell, int id) {
+__device__ inline void commit_cell(const GMaps &mp, const uint8_t *palette, int cell, int id) {
     mp.semantic_map[cell] = (uint32_t)id;
     const uint8_t *rgb = palette + 3 * id;
     const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];   // all three before the first store (which could alias them)
-    uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+    gptr<uint8_t> dst = mp.semantic_map_color + 3ll * cell;
     dst[0] = r; dst[1] = g; dst[2] = b;
 }
 
@@ -77,7 +77,7 @@ struct StreamArgs {
 // normalised entropy of the fused row.
 // MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
 template <int MODE, int V, int K, typename VecF>
-__device__ __forceinline__ void update_row(const View &v, int C, float log2_c, bool on, int sub, float *mrow,
+__device__ __forceinline__ void update_row(const View &v, int C, float log2_c, bool on, int sub, gptr<float> mrow,
                                            const VecF (&p)[K], VecF (&mv)[K], float w_old,
                                            int &bi, float &wn, float &ent_out) {
     // every product and sum rounds on its own, as numpy's array statements do (mapper.py:540-548):
@@ -118,7 +118,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + d * wgt;
                     sm += mv[k][j];
                 }
-                *reinterpret_cast<VecF *>(mrow + c) = mv[k];
+                *(gptr<VecF>)(mrow + c) = mv[k];
             }
         }
         sm = row_sum(sm);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + log_hw(q);
                     { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
                 }
-                *reinterpret_cast<VecF *>(mrow + c) = mv[k];
+                *(gptr<VecF>)(mrow + c) = mv[k];
             }
         }
     }
@@ -174,12 +174,13 @@ constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
 // The env's maps as the direct update writes them: the pointers once, in registers (read through
 // the struct they would be fetched again after every store, which could alias it).
 struct DirectMaps {
-    float *prob, *height, *weight, *unc;
-    uint32_t *gt, *sem;
-    uint8_t *color;
+    gptr<float> prob, height, weight, unc;
+    gptr<uint32_t> gt, sem;
+    gptr<uint8_t> color;
     __device__ __forceinline__ void take(const ssmap_env_maps &mp) {
-        prob = mp.prob_map; height = mp.height_map; weight = mp.weight_map; unc = mp.unc_map;
-        gt = mp.gt_map; sem = mp.semantic_map; color = mp.semantic_map_color;
+        prob = as_global(mp.prob_map); height = as_global(mp.height_map); weight = as_global(mp.weight_map);
+        unc = as_global(mp.unc_map); gt = as_global(mp.gt_map); sem = as_global(mp.semantic_map);
+        color = as_global(mp.semantic_map_color);
     }
 };
 
@@ -196,7 +197,7 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
     const float w_old = (UMODE == 1 && on) ? __builtin_bit_cast(float, __shfl(side, rowbase + 1)) : 0.0f;
     const int gtv = __shfl(side, rowbase + 2);
     const float hcand = __builtin_bit_cast(float, __shfl(side, rowbase + 3));
-    float *mrow = m.prob + (int64_t)cell * CT;
+    const gptr<float> mrow = m.prob + (int64_t)cell * CT;
     int bi;
     float wn, ent_out;
     update_row<UMODE, 1, K>(v, CT, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
@@ -213,13 +214,13 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
     // 32-bit map each, lanes 5..7 the colour bytes (after the row reductions every lane of the
     // row holds the same values)
     if (on) {
-        int *dst = nullptr;
+        gptr<int> dst = nullptr;
         int val = 0;
-        if (sub == 0) { dst = reinterpret_cast<int *>(m.height + cell); val = __builtin_bit_cast(int, hnew_v); }
-        if (sub == 1 && UMODE == 1) { dst = reinterpret_cast<int *>(m.weight + cell); val = __builtin_bit_cast(int, wn); }
-        if (sub == 2 && UMODE == 1) { dst = reinterpret_cast<int *>(m.unc + cell); val = __builtin_bit_cast(int, ent_out); }
-        if (sub == 3 && have_gt) { dst = reinterpret_cast<int *>(m.gt + cell); val = gtv; }
-        if (sub == 4) { dst = reinterpret_cast<int *>(m.sem + cell); val = id; }
+        if (sub == 0) { dst = (gptr<int>)(m.height + cell); val = __builtin_bit_cast(int, hnew_v); }
+        if (sub == 1 && UMODE == 1) { dst = (gptr<int>)(m.weight + cell); val = __builtin_bit_cast(int, wn); }
+        if (sub == 2 && UMODE == 1) { dst = (gptr<int>)(m.unc + cell); val = __builtin_bit_cast(int, ent_out); }
+        if (sub == 3 && have_gt) { dst = (gptr<int>)(m.gt + cell); val = gtv; }
+        if (sub == 4) { dst = (gptr<int>)(m.sem + cell); val = id; }
         if (dst) *dst = val;
         if (sub >= 5 && sub <= 7) m.color[3ll * cell + (sub - 5)] = (uint8_t)(rgb >> (8 * (sub - 5)));
     }
@@ -261,8 +262,8 @@ struct DirectRows {
     int n_blk, brank;     // owners in the block; this lane's number among them (if it owns a cell)
     bool owner;
     DirectMaps maps;
-    const int32_t *gt;
-    const float *hnew;
+    gptr<const int32_t> gt;
+    gptr<const float> hnew;
     int pix0;
 
     // row r of the pass = batch r / 4; batch j goes to wave j % 4 as its (j / 4)-th
@@ -291,11 +292,11 @@ struct DirectRows {
         const int sub = t & 15;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float *mrow = maps.prob + (int64_t)cell[b] * CT;
+            const gptr<const float> mrow = maps.prob + (int64_t)cell[b] * CT;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int c = V * (sub + 16 * k);
-                mv[b][k] = *reinterpret_cast<const VecF *>(mrow + (c < CT ? c : 0));
+                mv[b][k] = *(gptr<const VecF>)(mrow + (c < CT ? c : 0));
             }
         }
     }
@@ -304,10 +305,10 @@ struct DirectRows {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int opix = pix0 + othread[b];
-            const int *sp = reinterpret_cast<const int *>(maps.height + cell[b]);
-            if (sub == 1 && avg) sp = reinterpret_cast<const int *>(maps.weight + cell[b]);
+            gptr<const int> sp = (gptr<const int>)(maps.height + cell[b]);
+            if (sub == 1 && avg) sp = (gptr<const int>)(maps.weight + cell[b]);
             if (sub == 2 && gt) sp = gt + opix;
-            if (sub == 3) sp = reinterpret_cast<const int *>(hnew + opix);
+            if (sub == 3) sp = (gptr<const int>)(hnew + opix);
             side[b] = *sp;
         }
     }
@@ -316,7 +317,7 @@ struct DirectRows {
         // the env's map pointers once, in registers (read through the struct they would be fetched
         // again after every store, which could alias it)
         maps.take(v.envs[e].maps);
-        gt = gt_frame; hnew = hnew_frame; pix0 = block_pix0;
+        gt = as_global(gt_frame); hnew = as_global(hnew_frame); pix0 = block_pix0;
         s_cellw = cellw;
         owner = cellw >= 0;
         const unsigned long long owners = __ballot(owner);
@@ -689,10 +690,10 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
     // again after every store (the stores could alias the struct), one more round trip in front
     // of the row loads
     const ssmap_env_maps &mp_ref = v.envs[e].maps;
-    float *const m_prob = mp_ref.prob_map, *const m_height = mp_ref.height_map;
-    float *const m_weight = mp_ref.weight_map, *const m_unc = mp_ref.unc_map;
-    uint32_t *const m_gt = mp_ref.gt_map, *const m_sem = mp_ref.semantic_map;
-    uint8_t *const m_color = mp_ref.semantic_map_color;
+    const gptr<float> m_prob = as_global(mp_ref.prob_map), m_height = as_global(mp_ref.height_map);
+    const gptr<float> m_weight = as_global(mp_ref.weight_map), m_unc = as_global(mp_ref.unc_map);
+    const gptr<uint32_t> m_gt = as_global(mp_ref.gt_map), m_sem = as_global(mp_ref.semantic_map);
+    const gptr<uint8_t> m_color = as_global(mp_ref.semantic_map_color);
     const double agent_y = v.poses[e].agent[1];
     const int C = v.C;
     const float log2_c = log2f((float)C);
@@ -729,13 +730,13 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
                 cell[b] = live[b] ? pc.y : 0;
                 // unconditional loads (cell 0 / slot 0 / class 0 where there is nothing to do), the
                 // unused values are zeroed afterwards
-                const float *mrow = m_prob + (int64_t)cell[b] * C;
+                const gptr<const float> mrow = m_prob + (int64_t)cell[b] * C;
                 const float *prow = v.wprob + (fbase + (live[b] ? i : 0u)) * v.wprob_stride;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int c = V * (sub + 16 * k);
                     const int cs = c < C ? c : 0;
-                    mv[b][k] = *reinterpret_cast<const VecF *>(mrow + cs);
+                    mv[b][k] = *(gptr<const VecF>)(mrow + cs);
                     p[b][k] = *reinterpret_cast<const VecF *>(prow + cs);
                 }
                 w_old[b] = MODE == 1 ? m_weight[cell[b]] : 0.0f;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                float *mrow = m_prob + (int64_t)cell[b] * C;
+                const gptr<float> mrow = m_prob + (int64_t)cell[b] * C;
                 int bi;
                 float wn, ent_out;
                 update_row<MODE, V, K>(v, C, log2_c, live[b], sub, mrow, p[b], mv[b], w_old[b], bi, wn, ent_out);
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
             } else {
                 const uint8_t *rgb = v.palette + 3 * id;
                 const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];
-                uint8_t *dst = m_color + 3ll * cell;
+                gptr<uint8_t> dst = m_color + 3ll * cell;
                 dst[0] = r; dst[1] = g; dst[2] = b;
             }
         }

@@ -23,14 +23,14 @@ __device__ inline int occupancy_override(int id, float h, int use_height, int n_
     return id;
 }
 
-__device__ inline void paint(const ssmap_env_maps &mp, const uint8_t *palette, int cell, int id) {
+__device__ inline void paint(const GMaps &mp, const uint8_t *palette, int cell, int id) {
     const uint8_t *rgb = palette + 3 * id;
     const uint8_t r = rgb[0], g = rgb[1], b = rgb[2];   // all three before the first store (which could alias them)
-    uint8_t *dst = mp.semantic_map_color + 3ll * cell;
+    gptr<uint8_t> dst = mp.semantic_map_color + 3ll * cell;
     dst[0] = r; dst[1] = g; dst[2] = b;
 }
 
-__device__ inline float raise_height(const View &v, const ssmap_env_maps &mp, const PoseBlock &pb,
+__device__ inline float raise_height(const View &v, const GMaps &mp, const PoseBlock &pb,
                                      int64_t fbase, unsigned slot, int cell) {
     const double h = unorder_f64(v.wheight[fbase + slot]);
     const float hn = fmaxf(mp.height_map[cell], (float)(h - pb.agent[1]));
@@ -46,7 +46,7 @@ __device__ inline float nan_max(float a, float b) {
 // The goal statistics of one update cell (mapper.py:449-469) and, for the stubborn rule, the
 // naive-Bayes verdict on them (mapper.py:502-515): returns false when the model says "not the goal".
 // `pr` points at the pixel's probability in class plane 0; planes are N floats apart.
-__device__ inline bool goal_statistics(const View &v, const ssmap_env_maps &mp, const float *pr, int cell, int goal) {
+__device__ inline bool goal_statistics(const View &v, const GMaps &mp, const float *pr, int cell, int goal) {
     const int g = goal - 3;
     const int n_pool = v.pool_count[g];
     const int32_t *pool = v.pool_ids + g * SSMAP_MAX_POOL;
@@ -115,7 +115,7 @@ __global__ void k_hv_revert(View v) {
         if (blockIdx.x == 0 && threadIdx.x == 0) v.overlay_count[v.cur_overlay][e] = n;
         return;
     }
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = list[i];
         if (cell >= 0) mp.semantic_map[cell] = mp.background_map[cell];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict
     const int64_t fbase = (int64_t)e * v.N;
     const FrameHeader *hdr = v.hdr + e;
     const unsigned n = hdr->n_winners;
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     const PoseBlock pb = v.poses[e];
     const int goal = pb.goal_id;
     const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
@@ -276,7 +276,7 @@ __global__ void k_gd_scatter(View v, const int32_t *__restrict__ semantic, const
     int r0, c0, bh, bw;
     if (!gd_box(hdr, r0, c0, bh, bw)) return;
     const unsigned n = hdr->n_winners;
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     const PoseBlock pb = v.poses[e];
     const int goal = pb.goal_id;
     uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
@@ -361,7 +361,7 @@ __global__ void k_gd_apply(View v, int dil) {
     int r0, c0, bh, bw;
     if (!gd_box(hdr, r0, c0, bh, bw)) return;
     const bool any_goal = hdr->any_goal != 0;
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     const int goal = v.poses[e].goal_id;
     const uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
     const uint8_t *er = hdr->any_eroded ? v.local_eroded + (int64_t)e * v.local_stride : nullptr;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
     __shared__ int s_cand[kFoundThreads];
     __shared__ unsigned int s_n;
     const int e = blockIdx.y;
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     const PoseBlock pb = v.poses[e];
     if (pb.skip || (v.hdr[e].status & SSMAP_ENV_INDEX_ERROR)) return;   // no frame for this env, or one that raised: no decision, no rejection side effects
     const int goal = pb.goal_id;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
         for (unsigned k0 = 0; k0 < n_cand; k0 += 16) {     // same trip count for the whole block
             const unsigned k = k0 + row_id;
             const bool on = k < n_cand;
-            const float *m = mp.prob_map + (int64_t)(on ? s_cand[k] : 0) * C;
+            const gptr<float> m = mp.prob_map + (int64_t)(on ? s_cand[k] : 0) * C;
             // the cell's values of this lane (classes sub, sub + 16, ...) once, all loads in flight
             // together; the probability rules take at most 155 classes
             constexpr int kPer = 10;
@@ -566,7 +566,7 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
 __global__ void k_path_paint(View v) {
     const int e = blockIdx.y;
     const unsigned n = v.path_count[e];
-    const ssmap_env_maps mp = v.envs[e].maps;   // by value: the fields stay in registers across the stores below
+    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
     const int32_t *cells = v.path_cells + (int64_t)e * v.path_cap;
     const int id = v.n_schema + 1;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -586,11 +586,11 @@ void launch_path_paint(const View &v, uint32_t max_count, hipStream_t s) {
 // (what & 1), anywhere (what & 2)?  (env.py:581-604.)  One block per env; out[2 e], out[2 e + 1].
 __global__ __launch_bounds__(1024) void k_gt_goal(View v, int what, int32_t *__restrict__ out) {
     const int e = blockIdx.x;
-    const ssmap_env_maps mp = v.envs[e].maps;
+    const GMaps mp(v.envs[e].maps);
     const PoseBlock &pb = v.poses[e];
     const uint32_t goal = (uint32_t)pb.goal_id;
     // without probabilistic mapping the reference's gt_map is its semantic_map (mapper.py:257)
-    const uint32_t *gt = mp.gt_map ? mp.gt_map : mp.semantic_map;
+    const gptr<uint32_t> gt = mp.gt_map ? mp.gt_map : mp.semantic_map;
     int in_disk = 0, anywhere = 0;
     if (what & 2) {
         const int n = mp.map_h * mp.map_w;

@@ -84,6 +84,39 @@ struct NbModel {
     int32_t pad;
 };
 
+// Pointers typed as global memory.  A pointer that a kernel reads out of a struct in memory is a
+// generic (flat) pointer to the compiler; flat loads and stores count on both memory counters of a
+// wave, so every wait for an LDS access also waits for them, and their addresses are 64-bit register
+// pairs.  The maps are device allocations: their pointers are cast once, where they are taken.
+#define SSMAP_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+using gptr = SSMAP_GLOBAL T *;
+template <typename T>
+__host__ __device__ inline gptr<T> as_global(T *p) { return (gptr<T>)p; }
+
+// ssmap_env_maps as the kernels use it: by value, pointers typed as global memory.
+struct GMaps {
+    int32_t map_h, map_w;
+    double lower[3];
+    gptr<uint32_t> semantic_map;
+    gptr<uint8_t> semantic_map_color;
+    gptr<float> height_map;
+    gptr<uint32_t> gt_map;
+    gptr<float> unc_map, prob_map, weight_map, goal_map;
+    gptr<uint32_t> background_map;
+    gptr<float> hits, views;
+    gptr<uint32_t> total_view;
+    gptr<float> cumulative_conf, max_conf, max_other_conf;
+    __host__ __device__ explicit GMaps(const ssmap_env_maps &m)
+        : map_h(m.map_h), map_w(m.map_w), lower{m.lower[0], m.lower[1], m.lower[2]},
+          semantic_map(as_global(m.semantic_map)), semantic_map_color(as_global(m.semantic_map_color)),
+          height_map(as_global(m.height_map)), gt_map(as_global(m.gt_map)), unc_map(as_global(m.unc_map)),
+          prob_map(as_global(m.prob_map)), weight_map(as_global(m.weight_map)), goal_map(as_global(m.goal_map)),
+          background_map(as_global(m.background_map)), hits(as_global(m.hits)), views(as_global(m.views)),
+          total_view(as_global(m.total_view)), cumulative_conf(as_global(m.cumulative_conf)),
+          max_conf(as_global(m.max_conf)), max_other_conf(as_global(m.max_other_conf)) {}
+};
+
 struct EnvState {
     ssmap_env_maps maps;
     uint32_t n_overlay_prev;   // unused on host; kept for alignment

@@ -172,9 +172,12 @@ class SpPolicyFoundOverride:
         """After `mapper.update_map(...)` returned `true_found`: the overridden decision.  The two
         map questions are answered on the GPU from the maps in place (only those the branch reads)."""
         near = distance_to_vp < success_distance
+        # the engine answers for all of its envs: this mapper's own is env `mapper._e` (0 for a
+        # mapper of its own, the view's index inside a MapperGroup)
+        e = mapper._e
         in_disk, anywhere = mapper._engine.gt_goal_query(in_disk=bool(true_found), anywhere=bool(near))
-        found, fp, fn = sp_found_override([bool(true_found)], [True] if in_disk is None else in_disk,
-                                          [False] if anywhere is None else anywhere, [distance_to_vp],
+        found, fp, fn = sp_found_override([bool(true_found)], [True] if in_disk is None else in_disk[e:e + 1],
+                                          [False] if anywhere is None else anywhere[e:e + 1], [distance_to_vp],
                                           success_distance, [self.sp_fp_found])
         self.sp_fp_found = bool(fp[0])
         if fn[0] is not None:

@@ -200,3 +200,107 @@ def test_engine_skip_leaves_the_env_untouched(rule):
         assert n_upd[0] > 50
     for eng in engs:
         eng.close()
+
+
+def test_found_override_reads_the_views_own_env():
+    """SpPolicyFoundOverride on a view of a MapperGroup asks the engine about that view's env: the
+    views see different ground truth (only view 1's frames hold the goal), so env 0's answers on
+    view 1 would flip its latches."""
+    import semantic_search_amd as ssa
+    rule, c = "height_map_argmax", 8
+    frames, lut = _frames(rule, c, 3, 3, seed=21)
+    goal_idx = 0
+    for t in range(3):
+        for i in range(3):
+            obs = frames[t][i][0]
+            obs["objectgoal"] = np.array([goal_idx])
+            if i != 1:   # no goal in the ground truth of views 0 and 2
+                obs["semantic_gt"] = np.where(obs["semantic_gt"] == 3, 2, obs["semantic_gt"])
+            else:
+                obs["semantic_gt"] = np.full_like(obs["semantic_gt"], 3)
+    solo = [ssa.SemanticMapper(**_kw(rule, c)) for _ in range(3)]
+    group = ssa.MapperGroup(3, **_kw(rule, c))
+    for m in solo + group.mappers:
+        m.map_seg_to_schema = lambda ids: lut[ids]
+        m.reset(BOUNDS)
+    sp_solo = [ssa.SpPolicyFoundOverride() for _ in range(3)]
+    sp_view = [ssa.SpPolicyFoundOverride() for _ in range(3)]
+    differs = False
+    for t in range(3):
+        want = [solo[i].update_map(_copy(frames[t][i][0]), None) for i in range(3)]
+        got = group.update_maps([_copy(frames[t][i][0]) for i in range(3)])
+        for i in range(3):
+            # the found flag as the caller would pass it on; every branch is exercised by forcing it
+            for forced in (want[i][1], True):
+                a = sp_solo[i](solo[i], forced, 0.2, 1.0)
+                b = sp_view[i](group.mappers[i], forced, 0.2, 1.0)
+                assert (a, sp_solo[i].sp_fp_found, sp_solo[i].sp_fn_found) == \
+                       (b, sp_view[i].sp_fp_found, sp_view[i].sp_fn_found), (t, i, forced)
+        in_disk, anywhere = group._engine.gt_goal_query()
+        differs |= bool(anywhere[1]) and not bool(anywhere[0])
+    assert differs, "the views' ground truth should differ for this test to mean anything"
+    group.close()
+
+
+def test_goal_query_of_an_env_without_a_frame_since_bind_is_empty():
+    """An env that every step since its ssmap_bind_env skipped has no robot cell and no goal: both
+    answers of ssmap_gt_goal_query are 0, also after a reset in mid-run (the previous episode's
+    robot cell and goal must not be asked about)."""
+    import semantic_search_amd as ssa
+    rule, c, hw = "height_map_argmax", 8, (48, 64)
+    lut = scenes.small_lut(c)
+    rng = np.random.default_rng(4)
+    eng = ssa.MapEngine(2, hw, max_map_hw=ssa.map_size(BOUNDS, 0.03), **_kw(rule, c))
+    eng.set_schema(lut)
+    for e in range(2):
+        eng.reset_env(e, BOUNDS)
+
+    def step(skip):
+        fr, ag, cam = [], [], []
+        for e in range(2):
+            a, cm = scenes.make_pose(1.2 + 0.3 * e, 0.0, 1.3, np.pi + 0.75)
+            f = scenes.room_frame(rng, hw[0], hw[1], c, 1.0, cm, lut=lut)
+            f["semantic_gt"] = np.full_like(f["semantic_gt"], 3)
+            fr.append(f); ag.append(a); cam.append(cm)
+        dev = lambda key, dt: torch.from_numpy(np.stack([f[key] for f in fr]).astype(dt)).cuda()
+        eng.step(dev("depth", np.float32), np.stack(ag), np.stack(cam), [3, 3], skip=skip,
+                 semantic_gt=dev("semantic_gt", np.int32), semantic=dev("semantic", np.int32),
+                 semantic_unc=dev("semantic_unc", np.float32), semantic_max_prob=dev("semantic_max_prob", np.float32))
+        eng.results()
+
+    step([0, 1])                       # env 1 has never had a frame
+    in_disk, anywhere = eng.gt_goal_query()
+    assert bool(anywhere[0]) and not in_disk[1] and not anywhere[1]
+    step(None)                         # now it has: its gt_map holds the goal
+    in_disk, anywhere = eng.gt_goal_query()
+    assert bool(anywhere[1])
+    eng.reset_env(1, BOUNDS)           # new episode, then skipped again
+    step([0, 1])
+    in_disk, anywhere = eng.gt_goal_query()
+    assert not in_disk[1] and not anywhere[1] and bool(anywhere[0])
+    eng.close()
+
+
+def test_skipped_envs_are_not_validated():
+    """A skipped env's slices are neither read nor validated: a goal id outside [3, 8] there (what
+    an idle view leaves behind) does not fail a goal-statistics step of the other env."""
+    import semantic_search_amd as ssa
+    rule, c, hw = "height_map_argmax", 8, (48, 64)
+    lut = scenes.small_lut(c)
+    rng = np.random.default_rng(8)
+    eng = ssa.MapEngine(2, hw, max_map_hw=ssa.map_size(BOUNDS, 0.03), collect_nb_data=True, **_kw(rule, c))
+    eng.set_schema(lut)
+    for e in range(2):
+        eng.reset_env(e, BOUNDS)
+    a, cm = scenes.make_pose(1.2, 0.0, 1.3, np.pi + 0.75)
+    f = scenes.room_frame(rng, hw[0], hw[1], c, 1.0, cm, lut=lut)
+    dev = lambda key, dt: torch.from_numpy(np.stack([f[key], f[key]]).astype(dt)).cuda()
+    kw = dict(semantic_gt=dev("semantic_gt", np.int32), semantic=dev("semantic", np.int32),
+              semantic_unc=dev("semantic_unc", np.float32), semantic_max_prob=dev("semantic_max_prob", np.float32),
+              probs=dev("semantic_prob", np.float32))
+    eng.step(dev("depth", np.float32), np.stack([a, a]), np.stack([cm, cm]), [3, 0], skip=[0, 1], **kw)
+    found, status, n_upd = eng.results()
+    assert n_upd[0] > 50 and n_upd[1] == 0
+    with pytest.raises(Exception, match="goal id outside"):
+        eng.step(dev("depth", np.float32), np.stack([a, a]), np.stack([cm, cm]), [3, 0], **kw)
+    eng.close()

@@ -75,11 +75,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # SSMAP_LIB names another build of the same library (A/B timing of two builds on one box)
+    path = os.environ.get("SSMAP_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build the HIP engine first "
+            f"{path} is missing: build the HIP engine first "
             "(python semantic-search_amd/build.py); there is no CPU fallback")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int32
     lib.ssmap_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.ssmap_destroy.argtypes = [vp]

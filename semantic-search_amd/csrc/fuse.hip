@@ -76,7 +76,16 @@ struct StreamArgs {
 // row-local DPP steps.  Out: argmax class, and for the average family the new weight and the
 // normalised entropy of the fused row.
 // MODE 1: avg family (mapper.py:528-569), MODE 2: log-odds (mapper.py:574-603).
-template <int MODE, int V, int K, typename VecF>
+// THROUGH: the row is written with device-scope (write-through) stores; for the direct update, whose
+// scattered row stores run beside the streaming reads (V == 1 only).
+template <typename VecF>
+__device__ __forceinline__ void store_row(gptr<float> at, const VecF &val, bool through) {
+    if constexpr (sizeof(VecF) == 4) {
+        if (through) { __hip_atomic_store(at, val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+    *(gptr<VecF>)at = val;
+}
+template <int MODE, int V, int K, bool THROUGH = false, typename VecF>
 __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, bool on, int sub, gptr<float> mrow,
                                            const VecF (&p)[K], VecF (&mv)[K], float w_old,
                                            int &bi, float &wn, float &ent_out) {
@@ -118,7 +127,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + d * wgt;
                     sm += mv[k][j];
                 }
-                *(gptr<VecF>)(mrow + c) = mv[k];
+                store_row(mrow + c, mv[k], THROUGH);
             }
         }
         sm = row_sum(sm);
@@ -153,7 +162,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + log_hw(q);
                     { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
                 }
-                *(gptr<VecF>)(mrow + c) = mv[k];
+                store_row(mrow + c, mv[k], THROUGH);
             }
         }
     }
@@ -272,7 +281,7 @@ struct DirectRows {
     }
     // the owners r0 .. r0 + kDirectPre - 1 of the block leave their cell and thread in LDS, every
     // 16-lane row picks up the owner it will work on (block barriers inside)
-    __device__ __forceinline__ void exchange(DirectShared &sh, int t, int cellw, int r0) {
+    __device__ __forceinline__ void exchange(DirectShared &sh, const View &v, int t, int cellw, int r0) {
         if (owner && brank >= r0 && brank < r0 + kDirectPre) {
             sh.cell[brank - r0] = cellw;
             sh.thread[brank - r0] = t;
@@ -282,7 +291,7 @@ struct DirectRows {
         for (int b = 0; b < NB; ++b) {
             const int r = my_row(t, b);
             on[b] = r0 + r < n_blk;
-            cell[b] = on[b] ? sh.cell[r] : 0;
+            cell[b] = (on[b] && !(v.exp & 8)) ? sh.cell[r] : 0;
             othread[b] = on[b] ? sh.thread[r] : 0;
         }
         // (the slots are written again only by a later pass, behind the barriers of this pass's update)
@@ -333,7 +342,7 @@ struct DirectRows {
             n_blk += c;
         }
         brank = base + __popcll(owners & ((1ull << lane) - 1ull));
-        exchange(sh, t, cellw, 0);
+        exchange(sh, v, t, cellw, 0);
         load_side(t, avg);
         load_rows(t);
     }
@@ -342,11 +351,12 @@ struct DirectRows {
                                            const int (&lut_reg)[(CT + 63) / 64], int pal_reg, bool have_gt) {
         __shared__ __attribute__((aligned(16))) float s_rows[kDirectPre][CT];
         if (n_blk == 0) return;   // the same for the whole block
+        if (v.exp & 1) return;
         const int lane = t & 63, sub = lane & 15;
         const float log2_c = log2f((float)CT);
         for (int r0 = 0; r0 < n_blk; r0 += kDirectPre) {
             if (r0 > 0) {   // rare: more owners in the block than were requested ahead
-                exchange(sh, t, s_cellw, r0);
+                exchange(sh, v, t, s_cellw, r0);
                 load_side(t, UMODE == 1);
                 load_rows(t);
             }
@@ -361,10 +371,12 @@ struct DirectRows {
                 }
             }
             __syncthreads();
+            if (v.exp & 2) continue;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int r = my_row(t, b);
                 if (r0 + (r & ~3) >= n_blk) break;   // wave-uniform: no cell in this batch
+                if (v.exp & 4) on[b] = false;
                 VecF p[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -515,9 +527,20 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         }
         if (active) {
             const float unc = hsum * (-0.693147180559945309f / logf((float)CT));
-            if (a.sem_out) __builtin_nontemporal_store(sid, a.sem_out + fbase + pix);
-            if (a.unc_out) __builtin_nontemporal_store(unc, a.unc_out + fbase + pix);
-            if (a.maxp_out) __builtin_nontemporal_store(conf, a.maxp_out + fbase + pix);
+            // device-scope (write-through) stores: beside the streaming reads they measured 2-3 us
+            // faster than plain or nontemporal ones (tools/store_probe.hip)
+            // Stage 1 alone (the label rules' steps): device-scope (write-through) stores, 6 us faster
+            // at 40 classes than nontemporal ones beside the streaming reads; with a rule update in
+            // the kernel, or 150 classes, the nontemporal ones are (3-10 us)
+            if constexpr (MODE == 0 && CT <= 64) {
+                if (a.sem_out) __hip_atomic_store(a.sem_out + fbase + pix, sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.unc_out) __hip_atomic_store(a.unc_out + fbase + pix, unc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.maxp_out) __hip_atomic_store(a.maxp_out + fbase + pix, conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (a.sem_out) __builtin_nontemporal_store(sid, a.sem_out + fbase + pix);
+                if (a.unc_out) __builtin_nontemporal_store(unc, a.unc_out + fbase + pix);
+                if (a.maxp_out) __builtin_nontemporal_store(conf, a.maxp_out + fbase + pix);
+            }
             if (a.probs_out) {
                 float *dst = a.probs_out + ((int64_t)e * CT) * v.N + pix;
 #pragma unroll
@@ -794,7 +817,7 @@ __global__ __launch_bounds__(256) void k_update_prob(View v, const int32_t *__re
 template <int CT, int POOL>
 static void launch_reg_pool(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
     dim3 grid((v.N + kRegTile - 1) / kRegTile, v.E);
-    const size_t lds = POOL ? (size_t)(v.pool_slots > 0 ? v.pool_slots : 1) * kRegTile * sizeof(float) : 0;
+    const size_t lds = (POOL ? (size_t)(v.pool_slots > 0 ? v.pool_slots : 1) * kRegTile * sizeof(float) : 0) + (size_t)v.exp_lds;
     if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 2) hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);

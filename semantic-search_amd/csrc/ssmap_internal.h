@@ -188,6 +188,7 @@ struct View {
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;
     ssmap_params prm;
+    int32_t exp, exp_lds;      // measurement knobs (SSMAP_EXP, SSMAP_EXP_LDS)
 };
 
 __host__ __device__ inline unsigned long long order_f64(double h) {

@@ -2,7 +2,8 @@
 (tests/golden/make_stage1_golden.py ran EmsanetWrapper.predict and SegformerWrapper.predict of
 sem_objnav/segment/infer.py on synthetic network outputs; tests/golden/stage1/*.npz).
 
-CPU: the restatement (oracle/stage1_oracle.py) reproduces them bit for bit, and the class tables
+CPU: the restatement (oracle/stage1_oracle.py) reproduces them bit for bit (the entropy to the last
+place or two: torch's CPU logarithm differs between host CPUs), and the class tables
 the tests build their schema LUTs from are the reference's.  GPU: the HIP stage-1 kernels, through
 the C ABI, within rtol 1e-5 for the floats and exactly for the labels."""
 import glob
@@ -35,8 +36,15 @@ def test_oracle_reproduces_the_reference_tail(name):
     with np.errstate(all="ignore"):
         got = s1.predict_tail(data["logits"], meta["temperature"], data["lut"], table_order=meta["table_order"])
     assert np.array_equal(got["semantic"], data["semantic"])
-    for key in ("semantic_prob", "semantic_unc", "semantic_max_prob"):
+    for key in ("semantic_prob", "semantic_max_prob"):
         assert np.array_equal(got[key], data[key], equal_nan=True), key
+    # The entropy goes through torch's vectorised CPU logarithm, whose last bit depends on the host
+    # CPU: the reference's own predict() re-run on another machine of the same image differs from
+    # the recorded vectors in the last place of 2-4 % of the entropies (and only there).  Two ulp.
+    unc, want = got["semantic_unc"], data["semantic_unc"]
+    assert np.array_equal(np.isnan(unc), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert (np.abs(unc[ok].astype(np.float64) - want[ok]) <= 2.4e-7 * np.abs(want[ok]) + 1e-45).all(), "semantic_unc"
 
 
 @pytest.mark.gpu

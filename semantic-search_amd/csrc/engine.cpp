@@ -130,7 +130,6 @@ size_t carve_step_scratch(const ssmap_config &c, View &v, unsigned char *base) {
     take(v.target, prob_rule && !direct ? EN : 0);
     take(v.wprob, prob_rule && !direct ? EN * (size_t)c.n_classes : 0);
     take(v.ocell, direct ? EN : 0);
-    take(v.ohnew, direct ? EN : 0);
     take(v.winners, EN * 2);
     take(v.wheight, EN);
     const size_t local = c.rule == SSMAP_RULE_GOAL_DECAY ? E * 4 * (size_t)c.max_map_h * c.max_map_w : 0;

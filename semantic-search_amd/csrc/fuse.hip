@@ -19,6 +19,21 @@
 
 namespace ssmap {
 
+#ifndef SSMAP_SCHED_GROUP
+#define SSMAP_SCHED_GROUP 4
+#endif
+#ifndef SSMAP_WPE0
+#define SSMAP_WPE0 1
+#endif
+#ifndef SSMAP_WPE150
+#define SSMAP_WPE150 2
+#endif
+#ifndef SSMAP_WPE0MAX
+#define SSMAP_WPE0MAX 8
+#endif
+#ifndef SSMAP_WPED
+#define SSMAP_WPED 1
+#endif
 constexpr int kTile = 256;
 constexpr int kRegTile = 256;      // block of the register kernel (64 and 1024 threads measured slower)
 constexpr int kStride = kTile + 1;
@@ -183,29 +198,26 @@ constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
 // The env's maps as the direct update writes them: the pointers once, in registers (read through
 // the struct they would be fetched again after every store, which could alias it).
 struct DirectMaps {
-    gptr<float> prob, height, weight, unc;
-    gptr<uint32_t> gt, sem;
+    gptr<float> prob, weight, unc;
+    gptr<uint32_t> sem;
     gptr<uint8_t> color;
     __device__ __forceinline__ void take(const ssmap_env_maps &mp) {
-        prob = as_global(mp.prob_map); height = as_global(mp.height_map); weight = as_global(mp.weight_map);
-        unc = as_global(mp.unc_map); gt = as_global(mp.gt_map); sem = as_global(mp.semantic_map);
+        prob = as_global(mp.prob_map); weight = as_global(mp.weight_map);
+        unc = as_global(mp.unc_map); sem = as_global(mp.semantic_map);
         color = as_global(mp.semantic_map_color);
     }
 };
 
 // One 16-lane row finishes its cell: p = the owner pixel's probabilities, mv = the cell's fused
-// row (lane `sub` holds the classes sub + 16k), side = the cell's scalars in lanes 0..3 of the row
-// (old height, old weight, ground truth of the owner pixel, the owner pixel's height).  update_row,
-// then height map and ground-truth map (mapper.py:338-341, 361-363), label, colour.
+// row (lane `sub` holds the classes sub + 16k), cellw = the owner's word (the cell, and what the
+// occupancy override asks of the cell's new height: the winner kernel has raised the height map
+// and written the ground-truth map already).  update_row, then label and colour.
 template <int UMODE, int CT, int K, typename VecF>
-__device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, float log2_c, bool on, int lane, int cell,
-                                            int side, const VecF (&p)[K], VecF (&mv)[K],
-                                            const int (&lut_reg)[(CT + 63) / 64], int pal_reg, bool have_gt) {
-    const int sub = lane & 15, rowbase = lane & 48;
-    const float h_old = __builtin_bit_cast(float, __shfl(side, rowbase));
-    const float w_old = (UMODE == 1 && on) ? __builtin_bit_cast(float, __shfl(side, rowbase + 1)) : 0.0f;
-    const int gtv = __shfl(side, rowbase + 2);
-    const float hcand = __builtin_bit_cast(float, __shfl(side, rowbase + 3));
+__device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, float log2_c, bool on, int lane, int cellw,
+                                            float w_old, const VecF (&p)[K], VecF (&mv)[K],
+                                            const int (&lut_reg)[(CT + 63) / 64], int pal_reg) {
+    const int sub = lane & 15;
+    const int cell = cellw & (int)kCellMask;
     const gptr<float> mrow = m.prob + (int64_t)cell * CT;
     int bi;
     float wn, ent_out;
@@ -216,19 +228,19 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
         const int other = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[k]);
         sid = (bi >> 6) == k ? other : sid;
     }
-    const float hnew_v = fmaxf(h_old, hcand);
-    const int id = occupancy_override(sid, hnew_v, v.use_height, v.n_schema);
+    // occupancy override (mapper.py:556-569) from the two bits the winner kernel took of the new height
+    int id = sid;
+    if (v.use_height && v.n_schema == 9 && (unsigned)sid <= 2u)
+        id = (cellw & (int)kCellHighBit) ? 2 : ((cellw & (int)kCellLowBit) ? 1 : sid);
     const int rgb = __builtin_amdgcn_ds_bpermute((id & 63) << 2, pal_reg);
-    // the cell's scalars leave through two store instructions: lanes 0..4 of the row write one
+    // the cell's scalars leave through two store instructions: lanes 1, 2 and 4 of the row write one
     // 32-bit map each, lanes 5..7 the colour bytes (after the row reductions every lane of the
     // row holds the same values)
     if (on) {
         gptr<int> dst = nullptr;
         int val = 0;
-        if (sub == 0) { dst = (gptr<int>)(m.height + cell); val = __builtin_bit_cast(int, hnew_v); }
         if (sub == 1 && UMODE == 1) { dst = (gptr<int>)(m.weight + cell); val = __builtin_bit_cast(int, wn); }
         if (sub == 2 && UMODE == 1) { dst = (gptr<int>)(m.unc + cell); val = __builtin_bit_cast(int, ent_out); }
-        if (sub == 3 && have_gt) { dst = (gptr<int>)(m.gt + cell); val = gtv; }
         if (sub == 4) { dst = (gptr<int>)(m.sem + cell); val = id; }
         if (dst) *dst = val;
         if (sub >= 5 && sub <= 7) m.color[3ll * cell + (sub - 5)] = (uint8_t)(rgb >> (8 * (sub - 5)));
@@ -252,7 +264,7 @@ constexpr int kDirectPre = 32;   // owners per block (and pass) whose map rows a
 struct DirectShared {
     int count[kRegTile / 64];
     int cell[kDirectPre];
-    int thread[kDirectPre];
+    float scale[kDirectPre];   // average family: what turns an owner's parked row into probabilities
 };
 template <int CT>
 struct DirectRows {
@@ -266,33 +278,27 @@ struct DirectRows {
     typedef float VecF __attribute__((ext_vector_type(1)));
     typedef float VecS __attribute__((ext_vector_type(SV)));
     VecF mv[NB][K];
-    int side[NB], cell[NB], othread[NB];
+    float w_old[NB];      // average family: the cell's weight so far
+    int cell[NB];         // the owner's word: cell and height bits (kCellMask, kCellHighBit, kCellLowBit)
     bool on[NB];
     int n_blk, brank;     // owners in the block; this lane's number among them (if it owns a cell)
     bool owner;
     DirectMaps maps;
-    gptr<const int32_t> gt;
-    gptr<const float> hnew;
-    int pix0;
 
     // row r of the pass = batch r / 4; batch j goes to wave j % 4 as its (j / 4)-th
     __device__ __forceinline__ int my_row(int t, int b) const {
         return 4 * ((t >> 6) + (kRegTile / 64) * b) + ((t & 63) >> 4);
     }
-    // the owners r0 .. r0 + kDirectPre - 1 of the block leave their cell and thread in LDS, every
-    // 16-lane row picks up the owner it will work on (block barriers inside)
+    // the owners r0 .. r0 + kDirectPre - 1 of the block leave their word in LDS, every 16-lane row
+    // picks up the owner it will work on (block barriers inside)
     __device__ __forceinline__ void exchange(DirectShared &sh, const View &v, int t, int cellw, int r0) {
-        if (owner && brank >= r0 && brank < r0 + kDirectPre) {
-            sh.cell[brank - r0] = cellw;
-            sh.thread[brank - r0] = t;
-        }
+        if (owner && brank >= r0 && brank < r0 + kDirectPre) sh.cell[brank - r0] = cellw;
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int r = my_row(t, b);
             on[b] = r0 + r < n_blk;
             cell[b] = (on[b] && !(v.exp & 8)) ? sh.cell[r] : 0;
-            othread[b] = on[b] ? sh.thread[r] : 0;
         }
         // (the slots are written again only by a later pass, behind the barriers of this pass's update)
     }
@@ -301,7 +307,7 @@ struct DirectRows {
         const int sub = t & 15;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const gptr<const float> mrow = maps.prob + (int64_t)cell[b] * CT;
+            const gptr<const float> mrow = maps.prob + (int64_t)(cell[b] & (int)kCellMask) * CT;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int c = V * (sub + 16 * k);
@@ -309,24 +315,16 @@ struct DirectRows {
             }
         }
     }
-    __device__ __forceinline__ void load_side(int t, bool avg) {
-        const int sub = t & 15;
+    // the only per-cell scalar left to read: the average family's weight (every lane of the row
+    // asks for the same word)
+    __device__ __forceinline__ void load_side(bool avg) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int opix = pix0 + othread[b];
-            gptr<const int> sp = (gptr<const int>)(maps.height + cell[b]);
-            if (sub == 1 && avg) sp = (gptr<const int>)(maps.weight + cell[b]);
-            if (sub == 2 && gt) sp = gt + opix;
-            if (sub == 3) sp = (gptr<const int>)(hnew + opix);
-            side[b] = *sp;
-        }
+        for (int b = 0; b < NB; ++b) w_old[b] = avg ? maps.weight[cell[b] & (int)kCellMask] : 0.0f;
     }
-    __device__ __forceinline__ void request(DirectShared &sh, const View &v, int e, int t, int cellw,
-                                            const int32_t *gt_frame, const float *hnew_frame, int block_pix0, bool avg) {
+    __device__ __forceinline__ void request(DirectShared &sh, const View &v, int e, int t, int cellw, bool avg) {
         // the env's map pointers once, in registers (read through the struct they would be fetched
         // again after every store, which could alias it)
         maps.take(v.envs[e].maps);
-        gt = as_global(gt_frame); hnew = as_global(hnew_frame); pix0 = block_pix0;
         s_cellw = cellw;
         owner = cellw >= 0;
         const unsigned long long owners = __ballot(owner);
@@ -343,12 +341,12 @@ struct DirectRows {
         }
         brank = base + __popcll(owners & ((1ull << lane) - 1ull));
         exchange(sh, v, t, cellw, 0);
-        load_side(t, avg);
+        load_side(avg);
         load_rows(t);
     }
     template <int UMODE>
-    __device__ __forceinline__ void update(DirectShared &sh, const View &v, int t, const float (&x)[CT],
-                                           const int (&lut_reg)[(CT + 63) / 64], int pal_reg, bool have_gt) {
+    __device__ __forceinline__ void update(DirectShared &sh, const View &v, int t, const float (&x)[CT], float row_scale,
+                                           const int (&lut_reg)[(CT + 63) / 64], int pal_reg) {
         __shared__ __attribute__((aligned(16))) float s_rows[kDirectPre][CT];
         if (n_blk == 0) return;   // the same for the whole block
         if (v.exp & 1) return;
@@ -357,7 +355,7 @@ struct DirectRows {
         for (int r0 = 0; r0 < n_blk; r0 += kDirectPre) {
             if (r0 > 0) {   // rare: more owners in the block than were requested ahead
                 exchange(sh, v, t, s_cellw, r0);
-                load_side(t, UMODE == 1);
+                load_side(UMODE == 1);
                 load_rows(t);
             }
             if (owner && brank >= r0 && brank < r0 + kDirectPre) {
@@ -369,6 +367,7 @@ struct DirectRows {
                     for (int j = 0; j < SV; ++j) val[j] = x[SV * q + j];
                     *reinterpret_cast<VecS *>(row + SV * q) = val;
                 }
+                if (UMODE == 1) sh.scale[brank - r0] = row_scale;
             }
             __syncthreads();
             if (v.exp & 2) continue;
@@ -378,6 +377,10 @@ struct DirectRows {
                 if (r0 + (r & ~3) >= n_blk) break;   // wave-uniform: no cell in this batch
                 if (v.exp & 4) on[b] = false;
                 VecF p[K];
+                // the average family takes probabilities: the parked row times the owner's scale (the
+                // same product the streaming part forms where it normalises); log-odds are ratios
+                // within the row and take it as it is
+                const float rs = UMODE == 1 ? sh.scale[on[b] ? r : 0] : 1.0f;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int c = V * (sub + 16 * k);
@@ -385,11 +388,13 @@ struct DirectRows {
                     const bool used = on[b] && c < CT;
 #pragma unroll
                     for (int j = 0; j < V; ++j) {
+                        if (UMODE == 1) p[k][j] *= rs;
                         p[k][j] = used ? p[k][j] : 0.0f;
                         mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
                     }
                 }
-                direct_cell<UMODE, CT, K>(v, maps, log2_c, on[b], lane, cell[b], side[b], p, mv[b], lut_reg, pal_reg, have_gt);
+                direct_cell<UMODE, CT, K>(v, maps, log2_c, on[b], lane, cell[b], (UMODE == 1 && on[b]) ? w_old[b] : 0.0f,
+                                          p, mv[b], lut_reg, pal_reg);
             }
             if (r0 + kDirectPre < n_blk) __syncthreads();   // another pass reuses the LDS rows (the same for the whole block)
         }
@@ -405,7 +410,7 @@ struct DirectRows {
 // wider loads measured slower: the larger register footprint costs more occupancy than the
 // wider requests gain.)
 template <int CT, int MODE, int POOL>
-__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? 2 : 1, CT > 128 ? 2 : 8))) void k_stream_reg(View v, StreamArgs a) {
+__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? SSMAP_WPE150 : (MODE >= 3 ? SSMAP_WPED : SSMAP_WPE0), CT > 128 ? SSMAP_WPE150 : (MODE == 0 ? SSMAP_WPE0MAX : 8)))) void k_stream_reg(View v, StreamArgs a) {
     extern __shared__ float s_pool[];   // POOL: [pool_slots][kRegTile], a column per thread
     const int e = blockIdx.y;
     const int t = threadIdx.x;
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     // wave ends on a dependent gather through the saturated memory pipeline
     constexpr bool DIRECT = MODE >= 3;            // the owners' map cells are updated here (modes 3, 4)
     constexpr int UMODE = DIRECT ? MODE - 2 : MODE;   // 1: average family, 2: log-odds
+    constexpr bool NORM = MODE == 1 || MODE == 2;     // staged rows: the owners write probabilities
     constexpr int kLutRegs = (CT + 63) / 64;
     int lut_reg[kLutRegs];
     if (a.from_logits || DIRECT) {
@@ -459,9 +465,10 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
 #pragma unroll
     for (int c = 0; c < CT; ++c)
         x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+    float row_scale = 1.0f;   // what turns x into probabilities (1 / sum while x holds the exponentials)
     DirectRows<DIRECT ? CT : 4> dr;
     __shared__ DirectShared dsh;
-    if constexpr (DIRECT) dr.request(dsh, v, e, t, cellw, a.gt ? a.gt + fbase : nullptr, v.ohnew + fbase, blockIdx.x * kRegTile, UMODE == 1);
+    if constexpr (DIRECT) dr.request(dsh, v, e, t, cellw, UMODE == 1);
     if (a.from_logits) {
         // no implicit fused multiply-add in here: the roundings are those of the reference's
         // y = x / T, y - max(y)
@@ -472,19 +479,55 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         float m = -INFINITY;
 #pragma unroll
         for (int c = 0; c < CT; ++c) { x[c] *= a.inv_t; m = fmaxf(m, x[c]); }
+        // arg-max on the way: y - max is +0 exactly at the classes that reach the max and negative
+        // (sign bit set) at the others, so the unsigned minimum of bits(y - max) | c is the lowest
+        // class at the max, like argmax's tie rule (an or and half a three-way minimum per class)
         float s = 0.0f;
+        uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { x[c] = __builtin_amdgcn_exp2f((x[c] - m) * 1.44269504088896341f); s += x[c]; }
-        const float inv_s = 1.0f / s;
-        // the class at the max has exp2(0) = 1, so the largest probability is inv_s itself;
-        // ties go to the lowest class index like argmax does
-        float hsum = 0.0f;
-        int bi = 0;
+        for (int c = 0; c < CT; ++c) {
+            const float d = x[c] - m;
+            key = min(key, __builtin_bit_cast(uint32_t, d) | (uint32_t)c);
+            x[c] = __builtin_amdgcn_exp2f(d * 1.44269504088896341f);
+            s += x[c];
+            // (the tag chain is pinned here: it feeds only the label store, and sunk into that branch
+            // it would keep every difference alive beside the exponentials)
+            if (c % SSMAP_SCHED_GROUP == SSMAP_SCHED_GROUP - 1) { asm volatile("" : "+v"(key)); __builtin_amdgcn_sched_barrier(0); }
+        }
+        const float inv_s = 1.0f / s;   // the class at the max has exp2(0) = 1: the largest probability is inv_s itself
+        // (no class at the max: NaN logits; class 0 like an argmax over NaNs)
+        const int bi = (key >> 31) ? 0 : min((int)(key & 0xFFu), CT - 1);
+        float h_bits;   // entropy in bits
+        if constexpr (NORM || POOL) {
+            // the probabilities are taken for every pixel (staged rows, pooled confidence): formed in place
+            float hsum = 0.0f;
 #pragma unroll
-        for (int c = CT - 1; c >= 0; --c) {
-            x[c] *= inv_s;
-            hsum = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + 1e-6f), hsum);   // log2
-            bi = x[c] == inv_s ? c : bi;
+            for (int c = CT - 1; c >= 0; --c) {
+                x[c] *= inv_s;
+                hsum = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + 1e-6f), hsum);
+                if (c % SSMAP_SCHED_GROUP == 0) { asm volatile("" : "+v"(hsum)); __builtin_amdgcn_sched_barrier(0); }
+            }
+            h_bits = -hsum;
+        } else {
+            // from the exponentials as they are: with p = e / s,
+            //   -sum p log2(p + eps) = log2(s) - (1 / s) sum e log2(e + eps s),
+            // so no probability is formed per pixel; the direct update scales its few owner rows
+            const float eps_s = 1e-6f * s;
+            float hsum = 0.0f;
+#pragma unroll
+            for (int c = CT - 1; c >= 0; --c) {
+                hsum = __builtin_fmaf(x[c], __builtin_amdgcn_logf(x[c] + eps_s), hsum);
+                // (pinned like the tag chain: sunk into the branch of its store it would keep the
+                // exponentials alive beside whatever follows)
+                if (c % SSMAP_SCHED_GROUP == 0) { asm volatile("" : "+v"(hsum)); __builtin_amdgcn_sched_barrier(0); }
+            }
+            h_bits = __builtin_amdgcn_logf(s) - hsum * inv_s;
+            if (a.probs_out) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) x[c] *= inv_s;
+            } else {
+                row_scale = inv_s;
+            }
         }
         int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
 #pragma unroll
@@ -526,7 +569,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
             }
         }
         if (active) {
-            const float unc = hsum * (-0.693147180559945309f / logf((float)CT));
+            const float unc = h_bits * (0.693147180559945309f / logf((float)CT));
             // device-scope (write-through) stores: beside the streaming reads they measured 2-3 us
             // faster than plain or nontemporal ones (tools/store_probe.hip)
             // Stage 1 alone (the label rules' steps): device-scope (write-through) stores, 6 us faster
@@ -550,7 +593,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     }
     if (MODE == 0) return;
     if constexpr (DIRECT) {
-        dr.template update<UMODE>(dsh, v, t, x, lut_reg, pal_reg, a.gt != nullptr);
+        dr.template update<UMODE>(dsh, v, t, x, row_scale, lut_reg, pal_reg);
         return;
     }
 

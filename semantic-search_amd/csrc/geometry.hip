@@ -201,6 +201,7 @@ static_assert((1 << kBinShift) == kBinParts, "kBinShift must be log2 of kBinPart
 struct BinFrame {
     bool on;
     int rmin_b, cc0, per_row;
+    unsigned per_row_magic;   // floor(2^20 / per_row) + 1: (k * magic) >> 20 == k / per_row for k < 2048, per_row < 200
 };
 static_assert(kChunkShift == 3 && kRowSkew == 3, "geom_cell_table spells these constants out");
 __device__ inline int cell_table(uint32_t id) { return geom_cell_table(id); }
@@ -214,6 +215,9 @@ __device__ inline BinFrame bin_frame_box(const int32_t *box) {   // box = {rmin,
     const int cc1 = (cmax + kCoordBias) >> kChunkShift;
     f.per_row = (cc1 - f.cc0 + kBinParts) >> kBinShift;
     f.on = ((long long)(rmax - rmin + 1) * f.per_row << kChunkShift) <= kSlots;
+    // (a usable frame has at most kSlots / 8 chunks per table and, maps being at most 8192 cells
+    // wide, at most 65 chunks of a row per table)
+    f.per_row_magic = (1u << 20) / (unsigned)(f.per_row > 0 ? f.per_row : 1) + 1u;
     return f;
 }
 __device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
@@ -228,7 +232,8 @@ __device__ inline int cell_slot(const BinFrame &f, uint32_t id) {
 // inverse of (cell_table, cell_slot): unbiased cell of a slot of a table
 __device__ inline void slot_cell(const BinFrame &f, int table, int slot, int &row, int &col) {
     const int kc = slot >> kChunkShift;
-    const int row_rel = kc / f.per_row, kk = kc - row_rel * f.per_row;
+    static_assert((kSlots >> kChunkShift) <= 2048 && SSMAP_MAX_MAP_DIM / (8 * kBinParts) + 2 < 200, "range of the reciprocal");
+    const int row_rel = (int)(((unsigned)kc * f.per_row_magic) >> 20), kk = kc - row_rel * f.per_row;
     const int row_b = f.rmin_b + row_rel;
     const int j = ((table - f.cc0 - row_b * kRowSkew) & (kBinParts - 1)) + (kk << kBinShift);
     row = row_b - kCoordBias;
@@ -459,7 +464,8 @@ constexpr int kMaxGeomBlocksBinned = (kWinnerThreads / 64) * 64;
 struct WinnerShared {
     unsigned long long table_h[kSlots];
     unsigned int table_i[kSlots];
-    unsigned int s_base, s_neg;
+    unsigned int s_base, s_neg, s_total;
+    unsigned short comp[kSlots];           // the table's surviving slots, compacted in slot order
     unsigned int s_cnt[(kSlots / kWinnerThreads) * (kWinnerThreads / 64)];
     int s_box[kWinnerThreads / 64][4];
     GeomPart frame;                        // the geometry blocks' reports, folded
@@ -521,7 +527,15 @@ struct WinnerPre {
     double lower_x, lower_z;
     double cam_x, cam_y, cam_z, h_cut, agent_y;
     unsigned cnt;                    // bin_cnt of geometry block wave + 16 lane for table blockIdx.x
+    gptr<float> height_map;          // direct update: the winner kernel raises the height map and
+    gptr<uint32_t> gt_map;           // writes the ground-truth map itself (mapper.py:338-341, 361-363)
 };
+
+// The word the streaming kernel finds for a pixel that owns a map cell: the cell, and what the
+// occupancy override (mapper.py:556-569) will ask of the cell's new height.
+__device__ inline int owner_word(int cell, float hnew) {
+    return cell | (hnew > 0.1f ? (int)kCellHighBit : 0) | ((hnew != -INFINITY && hnew < 0.1f) ? (int)kCellLowBit : 0);
+}
 
 // One binned record in registers.  The not-updatable flag is not stored: a pixel in a table has
 // valid depth and lies inside the upper bounds, so it is updatable exactly when its height is
@@ -562,7 +576,8 @@ __device__ inline Rec<false> load_rec<false>(const View &v, int64_t at) {
 
 template <bool RUNS, bool PACKED>
 __device__ __forceinline__ void winners_body(const View &v, const float *__restrict__ depth_all, int write_target,
-                                             int write_list, WinnerShared &sh, const WinnerPre &pre) {
+                                             int write_list, WinnerShared &sh, const WinnerPre &pre,
+                                             const int32_t *__restrict__ gt_all, bool commit_now) {
     unsigned long long (&table_h)[kSlots] = sh.table_h;
     unsigned int (&table_i)[kSlots] = sh.table_i;
     unsigned int &s_base = sh.s_base, &s_neg = sh.s_neg;
@@ -743,9 +758,16 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
         __syncthreads();
         // phase c: emit the surviving slots in slot order (= row-major cell order), so that
-        // neighbouring list entries are neighbouring map cells
+        // neighbouring list entries are neighbouring map cells.  The surviving slots (an eighth of the
+        // table on a typical frame) are first compacted in LDS, so that the emission proper runs with
+        // every lane busy, one list entry per thread and trip.
+        // Direct update: height map and ground-truth map of the emitted cells are written here too,
+        // in that order (slots of a table are runs of eight neighbouring cells), and the owners' words
+        // carry what the occupancy override will ask of the new height: the streaming kernel then
+        // meets no per-cell scalar but the label.
         constexpr int kIters = kSlots / kWinnerThreads;
         const int lane = lane_id, wave = wave_id;
+        const bool commit = write_target == 2 && commit_now;
         unsigned long long balls[kIters];
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
@@ -767,17 +789,26 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             }
             s_cnt[2 * lane] = incl - c0 - c1;
             s_cnt[2 * lane + 1] = incl - c1;
-            if (lane == 63) s_base = incl ? atomicAdd(&hdr->n_winners, incl) : 0u;
+            if (lane == 63) {
+                sh.s_total = incl;
+                s_base = (incl && write_list) ? atomicAdd(&hdr->n_winners, incl) : 0u;
+            }
         }
         __syncthreads();
-        unsigned n_neg = 0;
-        // the slot layout once for the whole emission (read here, where the record registers are free)
-        const BinFrame bf = bin_frame(hdr);
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int s = it * kWinnerThreads + threadIdx.x;
-            if (!((balls[it] >> lane) & 1ull)) continue;
-            const unsigned w = table_i[s];
+        for (int it = 0; it < kIters; ++it)
+            if ((balls[it] >> lane) & 1ull)
+                sh.comp[s_cnt[it * kWaves + wave] + (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull))] =
+                    (unsigned short)(it * kWinnerThreads + threadIdx.x);
+        __syncthreads();
+        unsigned n_neg = 0;
+        const unsigned total = write_list ? sh.s_total : 0u;
+        // the slot layout once for the whole emission
+        const BinFrame bf = bin_frame(hdr);
+        for (unsigned j = threadIdx.x; j < total; j += kWinnerThreads) {
+            const int s = (int)sh.comp[j];
+            const int pix = (int)(table_i[s] >> 1);
+            const unsigned long long hk = table_h[s];
             int row, col;
             if (RUNS) {
                 slot_cell(bf, p, s, row, col);
@@ -793,19 +824,29 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
             // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
             const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
             const int cell = wr * Wm + wc;
-            const int pix = (int)(w >> 1);
             n_neg += (row < 0 || col < 0) ? 1u : 0u;
-            if (write_list) {
-                const unsigned pos = s_base + s_cnt[it * kWaves + wave] +
-                                     (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull));
-                if (write_target == 2) {
-                    v.ocell[fbase + pix] = cell;
-                    v.ohnew[fbase + pix] = (float)(unorder_f64(table_h[s]) - pre.agent_y);
-                } else if (write_target) { v.target[fbase + pix] = (int)pos; }
-                int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
-                const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
-                *out = make_int2((int)word, cell);
-                v.wheight[fbase + pos] = table_h[s];
+            float ho = 0.0f;
+            int gv = 0;
+            if (commit) {
+                ho = pre.height_map[cell];
+                if (gt_all) gv = gt_all[fbase + pix];
+            }
+            const unsigned pos = s_base + j;
+            int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
+            const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
+            *out = make_int2((int)word, cell);
+            v.wheight[fbase + pos] = hk;
+            if (commit) {
+                const float hn = fmaxf(ho, (float)(unorder_f64(hk) - pre.agent_y));
+                pre.height_map[cell] = hn;
+                if (gt_all) pre.gt_map[cell] = (uint32_t)gv;
+                v.ocell[fbase + pix] = owner_word(cell, hn);
+            } else if (write_target == 2) {
+                // a frame whose list may still change (wrapped cells, an IndexError candidate): the
+                // frame's last block writes the maps and the height bits once the list stands
+                v.ocell[fbase + pix] = cell;
+            } else if (write_target) {
+                v.target[fbase + pix] = (int)pos;
             }
         }
         if (n_neg) atomicAdd(&s_neg, n_neg);
@@ -865,6 +906,23 @@ __device__ inline void resolve_wrapped(const View &v, int e, unsigned n, int wri
             if (write_target == 2) v.ocell[fbase + pix] = -1;
             else if (write_target) v.target[fbase + pix] = -1;
         }
+    }
+}
+
+// Direct update, frames whose update list was not final when it was emitted: height map,
+// ground-truth map and the owners' words for every entry that kept its cell (one block).
+__device__ inline void commit_heights(const View &v, int e, unsigned n, const int32_t *__restrict__ gt_all,
+                                      gptr<float> height_map, gptr<uint32_t> gt_map, double agent_y) {
+    const int64_t fbase = (int64_t)e * v.N;
+    const int2 *list = reinterpret_cast<const int2 *>(v.winners) + fbase;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const int2 pc = list[i];
+        if ((uint32_t)pc.x & kLostBit) continue;
+        const int pix = (int)((uint32_t)pc.x & kPixMask);
+        const float hn = fmaxf(height_map[pc.y], (float)(unorder_f64(v.wheight[fbase + i]) - agent_y));
+        height_map[pc.y] = hn;
+        if (gt_all) gt_map[pc.y] = (uint32_t)gt_all[fbase + pix];
+        v.ocell[fbase + pix] = owner_word(pc.y, hn);
     }
 }
 
@@ -1002,6 +1060,7 @@ __device__ inline void withdraw_update_list(const View &v, int e, unsigned n, in
 // a ticket, and the block that takes the last one resolves the wrapped cells of the whole list.
 // Every block of a frame sees the same box and reports, so they agree on whether tickets are taken.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
+                                                            const int32_t *__restrict__ gt_all,
                                                             int write_target, int write_list) {
     __shared__ WinnerShared sh;
     __shared__ unsigned int s_last;
@@ -1020,6 +1079,8 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         pre.cam_x = pb.trans[0]; pre.cam_y = pb.trans[1]; pre.cam_z = pb.trans[2];
         pre.h_cut = pb.h_cut;
         pre.agent_y = pb.agent[1];
+        pre.height_map = as_global(mp.height_map);
+        pre.gt_map = as_global(mp.gt_map);
         const int b = (int)(threadIdx.x >> 6) + (kWinnerThreads / 64) * (int)(threadIdx.x & 63);
         pre.cnt = (v.geom_blocks <= kMaxGeomBlocksBinned && b < v.geom_blocks)
                       ? v.bin_cnt[((int64_t)e * kMaxParts + blockIdx.x) * v.geom_blocks + b] : 0u;
@@ -1035,11 +1096,14 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     }
     const int32_t box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
     const bool may_wrap = write_list && (sh.frame.spill || pre.rmin < 0 || pre.cmin < 0);
+    // the update list of such a frame may still change after it is emitted (every block of the
+    // frame sees the same box and reports, so they agree on it)
+    const bool deferred = may_wrap || err_candidate;
     if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)
-        winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre);
-    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre);
-    else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre);
-    if (!may_wrap && !err_candidate) return;
+        winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
+    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
+    else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
+    if (!deferred) return;
     __syncthreads();   // every thread's list entries and the block's header atomics are issued
     if (threadIdx.x == 0) {
         __threadfence();
@@ -1053,8 +1117,12 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         withdraw_update_list(v, e, write_list ? n_list : 0u, write_target);
         return;
     }
-    if (!may_wrap || __hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    resolve_wrapped(v, e, n_list, write_target);
+    if (may_wrap && __hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        resolve_wrapped(v, e, n_list, write_target);
+    if (write_target == 2 && write_list) {
+        __syncthreads();
+        commit_heights(v, e, n_list, gt_all, pre.height_map, pre.gt_map, pre.agent_y);
+    }
 }
 
 void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host_poses, hipStream_t s) {
@@ -1082,7 +1150,7 @@ void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, f.semantic_gt, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1);
 }
 
 }  // namespace ssmap

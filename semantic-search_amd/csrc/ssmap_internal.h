@@ -18,6 +18,10 @@ constexpr uint32_t kRowNegBit = 1u << 30;     // update-list pixel word: the cel
 constexpr uint32_t kColNegBit = 1u << 31;     // ... the cell column was negative (numpy wrap)
 constexpr uint32_t kLostBit = 1u << 29;       // ... another update pixel owns the same wrapped cell
 constexpr uint32_t kPixMask = (1u << 29) - 1;
+// direct update: the word a pixel's owner cell travels in (View::ocell)
+constexpr uint32_t kCellMask = (1u << 29) - 1;   // the map cell (maps have at most 8192 x 8192 cells)
+constexpr uint32_t kCellLowBit = 1u << 29;       // the cell's new height is below 0.1 (and not -inf): "free"
+constexpr uint32_t kCellHighBit = 1u << 30;      // the cell's new height is above 0.1: "occupied"
 constexpr int kSlots = 8192;                  // cells per LDS winner table
 constexpr int kSlotShift = 13;
 constexpr int kPackPixBits = 32 - kSlotShift;   // slot and pixel share one record word when N <= 2^19
@@ -152,8 +156,9 @@ struct View {
     uint32_t *rec_s;           // same shape: slot (only when !rec_packed)
     int32_t rec_packed;
     int32_t *target;           // [E][N] staged rows: the pixel's slot in the frame's update list, -1 = it owns no cell (cleared by the geometry kernel)
-    int32_t *ocell;            // [E][N] direct update (see direct_update): map cell a pixel owns this step, -1 = none
-    float *ohnew;              // [E][N] ... and its height above the agent, as the height map takes it (owners only)
+    int32_t *ocell;            // [E][N] direct update (see direct_update): map cell a pixel owns this step (kCellMask)
+                               //        with what the occupancy override asks of the cell's new height (kCellHighBit,
+                               //        kCellLowBit), -1 = the pixel owns no cell
     int32_t direct_update;     // the streaming kernel updates the owners' map cells itself (no staged rows, no update kernel)
     float *wprob;              // [E][N][wprob_stride] class probabilities of the update pixels, row = list slot
     int32_t wprob_stride;      // floats per row (>= C)

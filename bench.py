@@ -42,6 +42,21 @@ WORKLOADS = {
 }
 H, W = 480, 640
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# a class count none of the register streaming kernels is compiled for: the generic LDS-column path
+WORKLOADS["avg_prob_c21"] = dict(rule="height_map_avg_prob", C=21, T=3.2, span=14.39,
+                                 attrs=dict(entropy_threshold=0.43759))
+
+
+def bind_device(local_rank, world, backend):
+    """This rank's GPU, made current BEFORE the first call that touches a device (counting devices
+    does not): LOCAL_RANK -> cuda:LOCAL_RANK, one rank per GPU over RCCL like the reference's one
+    worker per device (eval_objnav.py:100).  With gloo (rehearsals) ranks may share a device."""
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        sys.exit(f"bench.py: {world} ranks but {n_dev} GPUs visible")
+    device = torch.device("cuda", local_rank % max(n_dev, 1))
+    torch.cuda.set_device(device)
+    return device
 
 
 def synth_frames(n_envs, n_classes, seed0, device):
@@ -191,71 +206,44 @@ def rehearse(args, rank, world):
 def kernel_registers(name):
     """VGPRs / waves per SIMD of a kernel from the committed compiler report."""
     import csv
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_kernel_resources.csv")) as fh:
-            for row in csv.DictReader(fh):
-                if row["kernel"] == name:
-                    return {"vgpr": int(row["VGPRs"]), "sgpr": int(row["TotalSGPRs"]),
-                            "waves_per_simd": int(row["Occupancy [waves/SIMD]"]),
-                            "lds_bytes_per_block": int(row["LDS Size [bytes/block]"])}
-    except (OSError, KeyError, ValueError):
-        pass
+    for tag in ("r3", "r2"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_resources.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    if row["kernel"] == name:
+                        return {"vgpr": int(row["VGPRs"]), "sgpr": int(row["TotalSGPRs"]),
+                                "waves_per_simd": int(row["Occupancy [waves/SIMD]"]),
+                                "lds_bytes_per_block": int(row["LDS Size [bytes/block]"]),
+                                "source": f"profiles/{tag}_kernel_resources.csv"}
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="log_odds_c40", choices=sorted(WORKLOADS))
-    ap.add_argument("--envs-per-gpu", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=60)
-    ap.add_argument("--min-seconds", type=float, default=0.5,
-                    help="the block of --steps steps is repeated until this much time has been measured")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="no GPU work: ranks only meet, reduce a dummy metric and rank 0 prints a stub line "
-                         "(a CPU check of the launch path; needs SSMAP_BENCH_BACKEND=gloo)")
-    args = ap.parse_args()
+def kernel_trace_us(workload, E, kernel_prefix):
+    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/r3_bench_<workload>_E<E>_kernel_stats.csv), or None."""
+    import csv
+    for tag in ("r3", "r2"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_bench_{workload}_E{E}_kernel_stats.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Name"].replace("void ", "").replace("ssmap::", "").startswith(kernel_prefix):
+                        return float(row["AverageNs"]) / 1e3, f"profiles/{tag}_bench_{workload}_E{E}_kernel_stats.csv"
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
-    if args.rehearse:
-        return rehearse(args, rank, world)
-    cpu_many = None
-    if world == 1 and not args.no_cpu_baseline:
-        # forked workers: before anything here initialises the GPU
-        n_procs = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
-        cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 8)
-    dist = None
-    # RCCL between the ranks of a node; SSMAP_BENCH_BACKEND=gloo lets several ranks share one GPU
-    # (a rehearsal of the multi-rank path on a one-GPU box: RCCL refuses two ranks on one device)
-    backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if backend == "nccl" and world > n_dev:
-        sys.exit(f"bench.py: {world} ranks but {n_dev} GPUs visible")
-    device = torch.device("cuda", local_rank % max(n_dev, 1))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-    torch.cuda.set_device(device)
 
+def measure(workload, E, args, rank, world, dist, device, backend):
+    """K steps of one workload between barriers (repeated to --min-seconds), then the same K steps
+    again with per-stage events.  Returns the numbers of this rank's view; the sums over ranks
+    are already reduced."""
     import semantic_search_amd as ssa
     from tests import scenes
 
-    wl = WORKLOADS[args.workload]
-    E, C = args.envs_per_gpu, wl["C"]
-    prob_rule = any(t in wl["rule"] for t in ("avg_prob", "log_odds"))
+    wl = WORKLOADS[workload]
+    C = wl["C"]
     span = wl["span"]
     map_hw = ssa.map_size([0, 0, 0, span, 3.0, span], 0.03)
     eng = ssa.MapEngine(E, (H, W), num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0),
@@ -266,6 +254,7 @@ def main():
     eng.set_schema(scenes.schema_lut(C))
     for e in range(E):
         eng.reset_env(e, [0, 0, 0, span, 3.0, span])
+    # one generator per env, seeded with the env's index in the whole job (rank * E + e)
     depth, logits, gt = synth_frames(E, C, rank * E, device)
     sem = torch.empty((E, H, W), dtype=torch.int32, device=device)
     unc = torch.empty((E, H, W), dtype=torch.float32, device=device)
@@ -322,35 +311,131 @@ def main():
                           dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(metric, op=dist.ReduceOp.SUM)   # the path's only exchange: final metric sum
-    frames_total = float(metric[0].item())
-    ranks_seen = int(metric[3].item())
+    out = dict(wl=wl, C=C, E=E, map_hw=map_hw, elapsed=elapsed, blocks=blocks,
+               stage_ms=[m / max(n_prof, 1) for m in stage_ms], k_mean=float(n_upd.mean()),
+               frames_total=float(metric[0].item()), ranks_seen=int(metric[3].item()))
+    eng.close()
+    del depth, logits, gt, sem, unc, maxp
+    torch.cuda.empty_cache()
+    return out
+
+
+def dominant_kernel(workload, m):
+    """Name, algorithmic bytes per launch and event-timed duration of the step's dominant kernel: the
+    streaming pass k_stream_* (one launch per step, stage group [2])."""
+    wl, C, E = m["wl"], m["C"], m["E"]
+    prob_rule = any(t in wl["rule"] for t in ("avg_prob", "log_odds"))
+    geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, m["k_mean"], prob_rule)
+    dom_bytes = s1_b * E
+    mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
+    # narrow class counts: the streaming kernel also updates the owners' map cells (modes 3, 4),
+    # so its compulsory bytes include the state traffic and no update kernel runs
+    direct = prob_rule and C in (8, 40) and os.environ.get("SSMAP_DIRECT", "1") != "0"
+    if direct:
+        mode += 2
+        dom_bytes += state_b * E
+    # third template argument: how the pooled goal confidence is staged (0: every goal pools one
+    # class, as the 40-class table does; 2: the SegFormer lists, known at compile time)
+    reg = C in (8, 33, 37, 40, 53, 81, 150)
+    name = f"k_stream_reg<{C}, {mode}, {2 if C == 150 else 0}>" if reg else f"k_stream_lds<{min(mode, 2)}>"
+    return name, direct, dom_bytes, (geo_b, s1_b, state_b)
+
+
+def workload_summary(workload, m, world):
+    """The short form of a measurement, for the `extras` block."""
+    name, direct, dom_bytes, (geo_b, s1_b, state_b) = dominant_kernel(workload, m)
+    fps = m["frames_total"] / m["elapsed"]
+    dom_ms = m["stage_ms"][2]
+    return {"workload": f"{m['wl']['rule']}, {m['E']} envs per GPU, {m['C']} classes, {m['map_hw'][0]}x{m['map_hw'][1]} map",
+            "value": fps, "unit": "frames/s", "ms_per_step": 1e3 * m["elapsed"] / m["steps"],
+            "algorithmic_MB_per_frame": (geo_b + s1_b + state_b) / 1e6,
+            "whole_path_frac_of_hbm_peak": (geo_b + s1_b + state_b) * (fps / world) / 1e9 / HBM_PEAK_GBS,
+            "dominant_kernel": name, "dominant_kernel_event_ms": dom_ms,
+            "dominant_kernel_frac_of_hbm_peak": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else None,
+            "stage_ms_per_step": dict(zip(STAGE_NAMES, m["stage_ms"]))}
+
+
+STAGE_NAMES = ("geometry", "winners", "stream_stage1", "rule_update", "found")
+EXTRA_WORKLOADS = ("avg_prob_c40", "w2_avg_prob_c150", "goal_decay_c40", "prob_hv_c40", "avg_prob_c21")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="log_odds_c40", choices=sorted(WORKLOADS) + ["all"],
+                    help="'all' = the default workload as the headline plus every other one in `extras`")
+    ap.add_argument("--envs-per-gpu", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extras` block (the other workloads at the same batch size, a short run each)")
+    ap.add_argument("--cpu-frames", type=int, default=60)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the block of --steps steps is repeated until this much time has been measured")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU work: ranks only meet, reduce a dummy metric and rank 0 prints a stub line "
+                         "(a CPU check of the launch path; needs SSMAP_BENCH_BACKEND=gloo)")
+    args = ap.parse_args()
+    want_extras = args.workload == "all" or (args.workload == "log_odds_c40" and not args.no_extras
+                                             and not args.no_cpu_baseline and args.gpus == 1)
+    if args.workload == "all":
+        args.workload = "log_odds_c40"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if args.rehearse:
+        return rehearse(args, rank, world)
+    cpu_many = None
+    if world == 1 and not args.no_cpu_baseline:
+        # forked workers: before anything here initialises the GPU
+        n_procs = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
+        cpu_many = (n_procs,) + cpu_baseline_processes(args.workload, n_procs, 8)
+    dist = None
+    # RCCL between the ranks of a node; SSMAP_BENCH_BACKEND=gloo lets several ranks share one GPU
+    # (a rehearsal of the multi-rank path on a one-GPU box: RCCL refuses two ranks on one device)
+    backend = os.environ.get("SSMAP_BENCH_BACKEND", "nccl")
+    device = bind_device(local_rank, world, backend)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    E = args.envs_per_gpu
+    m = measure(args.workload, E, args, rank, world, dist, device, backend)
+    m["steps"] = args.steps
+    extras = {}
+    if want_extras and world == 1:
+        short = argparse.Namespace(**vars(args))
+        short.steps, short.warmup, short.min_seconds = min(args.steps, 100), min(args.warmup, 10), 0.25
+        for name in EXTRA_WORKLOADS:
+            mx = measure(name, E, short, rank, world, None, device, backend)
+            mx["steps"] = short.steps
+            extras[name] = workload_summary(name, mx, world)
 
     if rank == 0:
-        k_mean = float(n_upd.mean())
-        geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, k_mean, prob_rule)
-        # dominant kernel = the streaming stage-1 pass (k_stream_*: one launch per step, stage
-        # group [2]): reads the [E][C][H][W] logits once, writes semantic / unc / max_prob
-        dom_ms = stage_ms[2] / max(n_prof, 1)
-        dom_bytes = s1_b * E
+        wl, C, map_hw = m["wl"], m["C"], m["map_hw"]
+        elapsed, blocks, frames_total = m["elapsed"], m["blocks"], m["frames_total"]
+        dom_name, direct, dom_bytes, (geo_b, s1_b, state_b) = dominant_kernel(args.workload, m)
+        # event interval around the kernel's launch on its stream: the kernel plus the ~3-5 us of one
+        # launch boundary and two event records; the committed kernel trace has the kernel alone
+        dom_ms = m["stage_ms"][2]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        trace_us, trace_src = kernel_trace_us(args.workload, E, dom_name.split("(")[0])
         traffic = None
         try:   # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 traffic = json.load(fh).get(args.workload, {}).get(f"E{E}", {}).get("k_stream_bytes_per_launch")
         except OSError:
             pass
-        mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
-        # narrow class counts: the streaming kernel also updates the owners' map cells (modes 3, 4),
-        # so its compulsory bytes include the state traffic and no update kernel runs
-        direct = prob_rule and C in (8, 40) and os.environ.get("SSMAP_DIRECT", "1") != "0"
-        if direct:
-            mode += 2
-            dom_bytes += state_b * E
-            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # third template argument: how the pooled goal confidence is staged (0: every goal pools one
-        # class, as the 40-class table does; 2: the SegFormer lists, known at compile time)
-        dom_name = f"k_stream_reg<{C}, {mode}, {2 if C == 150 else 0}>"
-        names = ("geometry", "winners", "stream_stage1", "rule_update", "found")
         line = {
             "metric": "map-fusion frames/sec (1 GPU and 8-GPU node) + % HBM peak, 640x480x40cls",
             "value": frames_total / elapsed,
@@ -367,8 +452,8 @@ def main():
             "config": {"workload": f"{wl['rule']}, {E} envs per GPU, 640x480 frames, {C} classes, "
                                    f"logits in (T={wl['T']}), {map_hw[0]}x{map_hw[1]} map",
                        "envs_per_gpu": E, "frames_per_step": E * world,
-                       "ranks": ranks_seen, "backend": backend if world > 1 else None,
-                       "mean_update_cells_per_frame": k_mean,
+                       "ranks": m["ranks_seen"], "backend": backend if world > 1 else None,
+                       "mean_update_cells_per_frame": m["k_mean"],
                        "algorithmic_MB_per_frame": (geo_b + s1_b + state_b) / 1e6,
                        "whole_path_frac_of_hbm_peak":
                            (geo_b + s1_b + state_b) * (frames_total / world / elapsed) / 1e9 / HBM_PEAK_GBS},
@@ -380,10 +465,22 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name + (" (stage 1 softmax/entropy pass fused with the rule update of the owners' map cells)" if direct else " (stage 1 fused softmax/entropy pass)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, committed (not collected in this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                         "avg_launch_ms_from": "HIP events recorded on the launch stream around the kernel, live in this run "
+                                               "(kernel + one launch boundary + the event records); `achieved` and `frac` use it",
+                         "kernel_trace_avg_launch_ms": trace_us / 1e3 if trace_us else None,
+                         "kernel_trace_frac": (dom_bytes / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if trace_us else None,
+                         "kernel_trace_source": trace_src,
                          "registers": kernel_registers(dom_name)},
-            "stage_ms_per_step": {nm: stage_ms[k] / max(n_prof, 1) for k, nm in enumerate(names)},
+            "stage_ms_per_step": dict(zip(STAGE_NAMES, m["stage_ms"])),
+            "stage_ms_note": "a second pass of the same K steps with six event records per step on the launch stream: "
+                             "every interval carries one launch boundary and an event record (about 3-5 us), so the "
+                             "five intervals add up to more than ms_per_step, which is measured without events",
         }
+        if extras:
+            line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             fps, n_done = cpu_baseline(args.workload, args.cpu_frames, seed=0, budget_s=12.0)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",

@@ -62,7 +62,8 @@ typedef enum ssmap_rule {
                                       raises IndexError at mapper.py:338, before its first map
                                       write; the step leaves this env's maps as they were */
 
-#define SSMAP_MAX_CLASSES 256
+#define SSMAP_MAX_CLASSES 155   /* largest n_classes ssmap_create accepts: class counts without a compiled
+                                   streaming kernel keep a frame tile's classes in one CU's LDS */
 #define SSMAP_MAX_MAP_DIM 8192
 #define SSMAP_MAX_POOL 8
 #define SSMAP_MAX_AUX 32

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libssmap.so")
 
-MAX_CLASSES = 256
+MAX_CLASSES = 155
 MAX_POOL = 8
 STATIC_SCRATCH_BYTES = 64 << 20
 

@@ -248,9 +248,9 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
         return fail(SSMAP_ERR_INVALID_ARG, "Invalid prob_aggregate");
     const bool prob_rule = c.rule >= SSMAP_RULE_AVG_PROB && c.rule <= SSMAP_RULE_LOG_ODDS;
     // the class tensor lives in LDS as [C][257] floats next to 2 KiB of bookkeeping
-    const int max_classes = (160 * 1024 - 4096) / (257 * 4);
-    if (c.n_classes < 0 || c.n_classes > max_classes || (prob_rule && c.n_classes < 1))
-        return fail(SSMAP_ERR_UNSUPPORTED, "n_classes must be in [1, 155] for the probability rules");
+    static_assert(SSMAP_MAX_CLASSES == (160 * 1024 - 4096) / (257 * 4), "the header's limit is the LDS limit");
+    if (c.n_classes < 0 || c.n_classes > SSMAP_MAX_CLASSES || (prob_rule && c.n_classes < 1))
+        return fail(SSMAP_ERR_UNSUPPORTED, "n_classes must be in [0, 155] (at least 1 for the probability rules)");
     if (c.max_map_h < 1 || c.max_map_w < 1 || c.max_map_h > SSMAP_MAX_MAP_DIM || c.max_map_w > SSMAP_MAX_MAP_DIM)
         return fail(SSMAP_ERR_INVALID_ARG, "map dimensions must be in [1, 8192]");
     if ((c.rule == SSMAP_RULE_HV || c.rule == SSMAP_RULE_PROB_HV) && !c.use_height_map)
@@ -319,7 +319,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
         TRY_ALLOC(dev_alloc(&v.overlay_count[i], (size_t)v.E));
         TRY_ALLOC(dev_zero(v.overlay_count[i], sizeof(uint32_t) * v.E));
     }
-    TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)SSMAP_MAX_CLASSES));
+    TRY_ALLOC(dev_alloc(&eng->d_lut, (size_t)32 * kClassWords));
     TRY_ALLOC(dev_alloc(&eng->d_pool_ids, (size_t)6 * SSMAP_MAX_POOL));
     TRY_ALLOC(dev_alloc(&eng->d_pool_count, (size_t)6));
     TRY_ALLOC(dev_alloc(&eng->d_query, (size_t)2 * v.E));
@@ -333,7 +333,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     TRY_ALLOC(dev_zero(eng->d_nb, 6 * sizeof(NbModel)));
     v.nb = eng->d_nb;
     TRY_ALLOC(dev_zero(eng->d_pool_count, 6 * sizeof(int32_t)));
-    TRY_ALLOC(dev_zero(eng->d_lut, SSMAP_MAX_CLASSES * sizeof(int32_t)));
+    TRY_ALLOC(dev_zero(eng->d_lut, 32 * kClassWords * sizeof(int32_t)));
 #undef TRY_ALLOC
     eng->h_poses.assign(c.n_envs, PoseBlock{});
     eng->last_poses.assign(c.n_envs, PoseBlock{});

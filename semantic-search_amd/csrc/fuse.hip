@@ -192,7 +192,7 @@ __host__ __device__ constexpr uint32_t ade_pool_word(int w) {
     for (int id : ids) if ((id >> 5) == w) m |= 1u << (id & 31);
     return m;
 }
-constexpr uint32_t kAdePoolMask[SSMAP_MAX_CLASSES / 32] = {
+constexpr uint32_t kAdePoolMask[kClassWords] = {
     ade_pool_word(0), ade_pool_word(1), ade_pool_word(2), ade_pool_word(3), ade_pool_word(4), 0, 0, 0};
 
 // The env's maps as the direct update writes them: the pointers once, in registers (read through

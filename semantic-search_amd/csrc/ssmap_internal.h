@@ -22,6 +22,8 @@ constexpr uint32_t kPixMask = (1u << 29) - 1;
 constexpr uint32_t kCellMask = (1u << 29) - 1;   // the map cell (maps have at most 8192 x 8192 cells)
 constexpr uint32_t kCellLowBit = 1u << 29;       // the cell's new height is below 0.1 (and not -inf): "free"
 constexpr uint32_t kCellHighBit = 1u << 30;      // the cell's new height is above 0.1: "occupied"
+constexpr int kClassWords = 8;                // 32-bit words of a bit per model class (room for 256 classes)
+static_assert(SSMAP_MAX_CLASSES <= 32 * kClassWords, "class masks");
 constexpr int kSlots = 8192;                  // cells per LDS winner table
 constexpr int kSlotShift = 13;
 constexpr int kPackPixBits = 32 - kSlotShift;   // slot and pixel share one record word when N <= 2^19
@@ -180,7 +182,7 @@ struct View {
     // for the register streaming kernel, by value: pool_mask bit c = class c is in some list; its
     // staging slot = number of such classes below c; pool_pack byte g * SSMAP_MAX_POOL + k = slot of the
     // k-th class of goal g's list, word 12 = six 4-bit list lengths; pool_slots = classes in lists
-    uint32_t pool_mask[SSMAP_MAX_CLASSES / 32];
+    uint32_t pool_mask[kClassWords];
     uint32_t pool_pack[13];
     int32_t pool_slots;
     int32_t *path_cells;       // [E][path_cap] cells of the agent's trail (path overlay)

@@ -229,9 +229,19 @@ class SemanticMapper:
                              agent_draw_radius_m=agent_draw_radius_m, aux_radius_m=aux_radius_m, aux_bin_m=aux_bin_m)
         self.path_width_px = int(path_width_m / pixel2meter)
         self.agent_radius_px = int(agent_draw_radius_m / pixel2meter)
+        # offsets of the auxiliary-angle squares from the image centre, in pixel coordinates
+        # (mapper.py:82-89: pol2cart of the bin angle, negated, truncated by the int32 cast)
+        aux_radius_px = int(aux_radius_m / pixel2meter)
+        self.aux_points = np.array(
+            [-np.array((aux_radius_px * np.cos(np.deg2rad(deg)), aux_radius_px * np.sin(np.deg2rad(deg))))
+             for deg in np.arange(0, 360, self.bin_size)], dtype=np.int32)
         self.color_pallete = _engine.colormap(num_semantic_classes + 3)
+        self.active_goal_color = self.color_pallete[num_semantic_classes]          # mapper.py:103
         self.path_color = np.array([128, 0, 128], dtype=np.uint8)
         self.color_pallete[num_semantic_classes + 1] = self.path_color
+        self.arrow_color = tuple(int(c) for c in self.color_pallete[num_semantic_classes + 2])   # mapper.py:106-108
+        self.aux_pred_color = np.array([255, 255, 255], dtype=np.uint8)             # mapper.py:109
+        self.log_data = {}                                                          # mapper.py:144
         self.path_id = num_semantic_classes + 1
         self.height_cutoff_m = height_cutoff_m
         self.probablistic_mapping = probablistic_mapping

@@ -52,3 +52,15 @@ def labels_agree(sem, want_sem, fused_want, name="semantic_map", margin=1e-5):
     goal = np.isin(sem[bad], GOAL_IDS) | np.isin(want_sem[bad], GOAL_IDS)
     assert not goal.any(), f"{name}: a goal label differs on {goal.sum()} cells"
     return int(bad.sum())
+
+
+def elementwise_relative(got, want, floor=1e-3):
+    """Element-wise relative error over the finite entries with |want| >= floor:
+    (largest, fraction of those entries above 1e-5, number of entries)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    sel = np.isfinite(want) & np.isfinite(got) & (np.abs(want) >= floor)
+    if not sel.any():
+        return 0.0, 0.0, 0
+    rel = np.abs(got[sel] - want[sel]) / np.abs(want[sel])
+    return float(rel.max()), float((rel > 1e-5).mean()), int(sel.sum())

@@ -88,3 +88,54 @@ def test_bench_refuses_more_ranks_than_gpus():
     res = _bench("--gpus", str(n + 2), "--no-cpu-baseline")
     assert res.returncode != 0
     assert "visible" in res.stderr and not any(ln.startswith("{") for ln in res.stdout.splitlines())
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_binds_local_rank_to_its_device_before_anything_touches_a_gpu(monkeypatch):
+    """One rank per GPU: rank r of a node must make cuda:r current before the process group, the
+    engine or any tensor exists (a rank that initialises device 0 first leaves a context there and
+    RCCL then sees two ranks on one device)."""
+    import inspect
+    bench = _load_bench()
+    calls = []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", str(d))))
+    for lr in (0, 5, 7):
+        dev = bench.bind_device(lr, 8, "nccl")
+        assert str(dev) == f"cuda:{lr}" and calls[-1] == ("set_device", f"cuda:{lr}")
+    # more ranks than devices is refused for RCCL, allowed (shared devices) for a gloo rehearsal
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    try:
+        bench.bind_device(3, 4, "nccl")
+        assert False, "four RCCL ranks on two GPUs must be refused"
+    except SystemExit:
+        pass
+    assert str(bench.bind_device(3, 4, "gloo")) == "cuda:1"
+    # order inside main(): device binding, then the process group, then the engine
+    src = inspect.getsource(bench.main)
+    at = [src.index(tok) for tok in ("bind_device(", "init_process_group(", "measure(")]
+    assert at == sorted(at)
+    assert "device_id=device" in src, "the RCCL process group is bound to this rank's device"
+    # measure() seeds the envs of rank r with r * E + e and builds everything on `device`
+    msrc = inspect.getsource(bench.measure)
+    assert "synth_frames(E, C, rank * E, device)" in msrc and "device=device" in msrc
+
+
+def test_bench_frames_depend_only_on_the_global_env_index():
+    """Env e of rank r is frame number r * E + e of the job whatever the rank count: two ranks of
+    two envs see the frames one rank of four envs sees."""
+    bench = _load_bench()
+    cpu = torch.device("cpu")
+    whole = bench.synth_frames(3, 1, 0, cpu)
+    part = bench.synth_frames(1, 1, 2, cpu)     # rank 2 of a job with one env per rank
+    for a, b in zip(whole, part):
+        assert torch.equal(a[2], b[0])
+    assert not torch.equal(whole[0][0], whole[0][1])

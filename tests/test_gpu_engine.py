@@ -16,6 +16,10 @@ from tests import parity, scenes
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-5, 1e-6
+# Worst element-wise relative error of a log-odds entry (|x| >= 1e-3) on the full-size frames: the
+# hardware logarithm is good to an ulp or two of log2(q), i.e. an absolute 2e-7 on a term of
+# magnitude 1-10; an entry that cancels to 1e-3 keeps that absolute error.
+ELEMENTWISE_LOG_ODDS_BOUND = 1e-3
 BOUNDS_480 = np.array([0.0, 0.0, 0.0, 14.39, 3.0, 14.39])
 
 
@@ -206,7 +210,7 @@ def _run_pair(rule, n_classes, temperature, n_frames, hw, from_logits, attrs=Non
 
 
 @pytest.mark.parametrize("rule,from_logits", [
-    ("height_map_log_odds", True), ("height_map_avg_prob", True), ("height_map_avg_prob", False),
+    ("height_map_log_odds", True), ("height_map_log_odds", False), ("height_map_avg_prob", True), ("height_map_avg_prob", False),
     ("height_map_w_avg_prob", True), ("height_map_w2_avg_prob", False)])
 def test_full_size_probability_rules(rule, from_logits):
     """640x480x40 benchmark-recipe frames, two frames, fused state vs the oracle."""
@@ -217,6 +221,12 @@ def test_full_size_probability_rules(rule, from_logits):
     want = getattr(ref, name)
     if "log_odds" in rule:
         parity.close_rows(got, want, name)          # relative to the cell's largest |log-odds|
+        # ... and element by element: an entry is a sum of a few log(p_c / p_0) that can cancel, so
+        # its own magnitude is a harder yardstick than its cell's; the worst entry is reported
+        worst, above, n = parity.elementwise_relative(got, want, floor=1e-3)
+        print(f"\n{name}: element-wise relative error over {n} entries with |x| >= 1e-3: worst {worst:.2e}, "
+              f"{100 * above:.4f} % above 1e-5")
+        assert worst <= ELEMENTWISE_LOG_ODDS_BOUND, worst
     else:
         _close(got, want, name)
     if rule == "height_map_avg_prob" and not from_logits:
@@ -225,6 +235,8 @@ def test_full_size_probability_rules(rule, from_logits):
     assert np.array_equal(maps["gt_map"].cpu().numpy().view(np.uint32), ref.gt_map)
     sem = maps["semantic_map"].cpu().numpy().view(np.uint32)
     flips = parity.labels_agree(sem, ref.semantic_map, want)
+    print(f"\n{rule}: {flips} of {int((ref.semantic_map != 0).sum())} labelled cells differ from the oracle's "
+          "(top-2 within 1e-5, no goal id)")
     if "avg" in rule:
         _close(maps["unc_map"].cpu().numpy(), ref.unc_map, "unc_map")
     if not flips:

@@ -70,6 +70,16 @@ def test_mapper_exposes_rule_attributes_like_the_reference():
     assert (gd.goal_decay, gd.goal_mark) == (0.9, 2.0)
     assert gd.goal2sem_id.tolist() == [3, 4, 5, 6, 7, 8] and gd.path_id == 10
     assert gd.unc_map is None        # before reset, like the reference
+    # the drawing constants of the constructor (mapper.py:82-89, 103-109, 144)
+    assert gd.aux_points.shape == (12, 2) and gd.aux_points.dtype == np.int32
+    r = int(0.4 / 0.03)
+    want = np.array([-np.array((r * np.cos(np.deg2rad(d)), r * np.sin(np.deg2rad(d)))) for d in np.arange(0, 360, 30.0)],
+                    dtype=np.int32)
+    assert np.array_equal(gd.aux_points, want) and gd.aux_points[0].tolist() == [-13, 0]
+    assert np.array_equal(gd.active_goal_color, gd.color_pallete[9])
+    assert gd.arrow_color == tuple(int(c) for c in gd.color_pallete[11]) and all(isinstance(c, int) for c in gd.arrow_color)
+    assert gd.aux_pred_color.tolist() == [255, 255, 255] and gd.aux_pred_color.dtype == np.uint8
+    assert gd.log_data == {}
     with pytest.raises(RuntimeError, match="Invalid prob_aggregate"):
         ssa.SemanticMapper(prob_aggregate="height_map_bogus", **kw)
 

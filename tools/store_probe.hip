@@ -100,7 +100,7 @@ static void run(const char *name, const float *in, float *out, float *map, const
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **) {
     float *in, *out, *map;
     int *cells;
     const size_t n_in = (size_t)kE * kC * kN;
@@ -125,6 +125,26 @@ int main() {
 #define RUN(S, R, W, ST) run<S, R, W, ST>("stride " #S " rd " #R " wr " #W " stream " #ST, in, out, map, cells)
 #define RUNA(S, R, W, ST, AW, AR) run<S, R, W, ST, AW, AR>("stride " #S " rd " #R " wr " #W " stream " #ST " auxw " #AW " auxr " #AR, in, out, map, cells)
 #define RUNO(W, AW, AO) run<40, W, W, 1, AW, 2, AO>("3 out planes, rmw " #W " auxw " #AW " auxo " #AO, in, out, map, cells)
+#define RUNS(S, R, W, AW) run<S, R, W, 1, AW, 2, 16>("3 out planes (sc1), stride " #S " rd " #R " wr " #W " auxw " #AW, in, out, map, cells)
+    if (argc > 1) {
+        // second table: row strides and store widths beside the full stage-1 traffic
+        RUNS(40, 0, 0, 0);
+        RUNS(40, 1, 0, 0);
+        RUNS(40, 1, 1, 0);
+        RUNS(40, 0, 1, 0);
+        RUNS(40, 1, 1, 2);
+        RUNS(40, 1, 1, 16);
+        RUNS(40, 1, 1, 17);
+        RUNS(40, 1, 3, 0);
+        RUNS(48, 1, 1, 0);
+        RUNS(48, 1, 2, 0);
+        RUNS(48, 1, 3, 0);
+        RUNS(64, 1, 1, 0);
+        RUNS(64, 1, 2, 0);
+        RUNS(64, 1, 3, 0);
+        RUNS(64, 1, 4, 0);
+        return 0;
+    }
     RUNA(40, 0, 0, 1, 0, 2);
     RUNO(0, 0, 0);
     RUNO(0, 0, 1);

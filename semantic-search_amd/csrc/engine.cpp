@@ -301,6 +301,8 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     eng->step_bytes = carve_step_scratch(c, v, nullptr);
     TRY_ALLOC(dev_alloc(&eng->d_step, eng->step_bytes));
     carve_step_scratch(c, v, eng->d_step);
+    // goal_decay's local maps start out zero and every step leaves them zero (k_found)
+    if (v.local_ids) TRY_ALLOC(dev_zero(v.local_ids, (size_t)v.E * v.local_stride));
     // this device's address of the file-scope scratch array (ssmap_step_noalloc)
     {
         void *sym = nullptr;
@@ -821,6 +823,7 @@ static int step_impl(ssmap_engine *eng, const ssmap_frames *f, void *stream_v, b
     // the view the kernels get: the engine's, with the per-step scratch at its home for this call
     View lv = v;
     if (static_home) carve_step_scratch(c, lv, eng->d_static);
+    lv.local_clean = static_home ? 0 : 1;   // the shared static array holds whatever its last user left
     eng->last_list = lv.winners;
     hipEvent_t *marks = nullptr;
     if (eng->prof_capacity && eng->prof_steps < eng->prof_capacity)

@@ -1053,6 +1053,34 @@ __device__ inline void withdraw_update_list(const View &v, int e, unsigned n, in
     }
 }
 
+// hv rules rebuild semantic_map from background_map every frame (mapper.py:662, 723); the engine keeps
+// semantic_map == background_map except on the cells that showed the goal overlay last frame, and
+// undoes that list here, ahead of this frame's rule kernel, instead of copying the whole map.  The
+// list has one entry per slot of last frame's update list: the cell if it showed the overlay, -1 if
+// not.  Entries first, first + stride, ... (a slice per winner block, or the whole list for one block).
+__device__ inline void hv_revert_overlay(const View &v, int e, unsigned first, unsigned stride) {
+    const int prev = v.cur_overlay ^ 1;
+    const unsigned n = v.overlay_count[prev][e];
+    const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
+    const ssmap_env_maps &mp = v.envs[e].maps;
+    const gptr<uint32_t> sem = as_global(mp.semantic_map);
+    const gptr<const uint32_t> bg = as_global(mp.background_map);
+    for (unsigned i = first; i < n; i += stride) {
+        const int cell = list[i];
+        if (cell >= 0) sem[cell] = bg[cell];
+    }
+}
+// An env without a frame in this step, or whose frame raised IndexError, keeps last frame's overlay
+// on its map: the list moves on to the buffer the next step will undo.
+__device__ inline void hv_keep_overlay(const View &v, int e, unsigned first, unsigned stride, bool write_count) {
+    const int prev = v.cur_overlay ^ 1;
+    const unsigned n = v.overlay_count[prev][e];
+    const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
+    int32_t *keep = v.overlay[v.cur_overlay] + (int64_t)e * v.N;
+    for (unsigned i = first; i < n; i += stride) keep[i] = list[i];
+    if (write_count) v.overlay_count[v.cur_overlay][e] = n;
+}
+
 // Frames whose predicted cell box fits the 16 tables and holds every live pixel are read as
 // per-table record ranges; the others (spilled) are scanned pixel by pixel, once per table.
 // Only a frame whose cell box reaches below zero, or a spilled one, can hold wrapped cells: the
@@ -1061,12 +1089,16 @@ __device__ inline void withdraw_update_list(const View &v, int e, unsigned n, in
 // Every block of a frame sees the same box and reports, so they agree on whether tickets are taken.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
                                                             const int32_t *__restrict__ gt_all,
-                                                            int write_target, int write_list) {
+                                                            int write_target, int write_list, int hv_rule) {
     __shared__ WinnerShared sh;
     __shared__ unsigned int s_last;
     const int e = blockIdx.y;
     FrameHeader *hdr = v.hdr + e;
-    if (v.poses[e].skip) return;   // no frame for this env (its header says zero update cells)
+    const unsigned hv_first = blockIdx.x * kWinnerThreads + threadIdx.x, hv_stride = gridDim.x * kWinnerThreads;
+    if (v.poses[e].skip) {   // no frame for this env (its header says zero update cells)
+        if (hv_rule) hv_keep_overlay(v, e, hv_first, hv_stride, blockIdx.x == 0 && threadIdx.x == 0);
+        return;
+    }
     // every first load of the block in one group: the latencies overlap instead of adding up
     const ReportRegs rep = load_reports(v, e);
     WinnerPre pre;
@@ -1090,6 +1122,8 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     fold_reports(rep, sh);
     // an index-error report of the geometry kernel is a candidate: the frame's last block decides
     const bool err_candidate = (sh.frame.err & SSMAP_ENV_INDEX_ERROR) != 0u;
+    // (a frame that may still raise leaves last frame's overlay to its last block, which knows)
+    if (hv_rule && !err_candidate) hv_revert_overlay(v, e, hv_first, hv_stride);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->min_invalid_pixel = sh.frame.min_invalid_pixel;
         if (sh.frame.err & ~(uint32_t)SSMAP_ENV_INDEX_ERROR) atomicOr(&hdr->status, sh.frame.err & ~(uint32_t)SSMAP_ENV_INDEX_ERROR);
@@ -1115,8 +1149,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     const unsigned n_list = __hip_atomic_load(&hdr->n_winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__builtin_expect(err_candidate, 0) && index_error_confirmed(v, depth_all + (int64_t)e * v.N, e, sh)) {
         withdraw_update_list(v, e, write_list ? n_list : 0u, write_target);
+        if (hv_rule) hv_keep_overlay(v, e, threadIdx.x, blockDim.x, threadIdx.x == 0);
         return;
     }
+    if (hv_rule && err_candidate) hv_revert_overlay(v, e, threadIdx.x, blockDim.x);
     if (may_wrap && __hip_atomic_load(&hdr->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         resolve_wrapped(v, e, n_list, write_target);
     if (write_target == 2 && write_list) {
@@ -1150,7 +1186,8 @@ void launch_geometry(const View &v, const ssmap_frames &f, const PoseBlock *host
 void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, f.semantic_gt, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1);
+    const int hv_rule = (v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV) ? 1 : 0;
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, f.semantic_gt, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1, hv_rule);
 }
 
 }  // namespace ssmap

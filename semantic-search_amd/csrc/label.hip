@@ -98,30 +98,6 @@ __device__ inline bool goal_statistics(const View &v, const GMaps &mp, const flo
     return label != 0;
 }
 
-// hv rules rebuild semantic_map from background_map every frame (mapper.py:662, 723); the
-// engine keeps semantic_map == background_map except on the cells listed here, and undoes
-// last frame's list instead of copying the whole map.  The list has one entry per slot of that
-// frame's update list: the cell if it showed the goal overlay, -1 if not.
-__global__ void k_hv_revert(View v) {
-    const int e = blockIdx.y;
-    const int prev = v.cur_overlay ^ 1;
-    const unsigned n = v.overlay_count[prev][e];
-    const int32_t *list = v.overlay[prev] + (int64_t)e * v.N;
-    if (v.poses[e].skip || (v.hdr[e].status & SSMAP_ENV_INDEX_ERROR)) {
-        // no frame for this env (or one that raised IndexError): its map keeps last frame's overlay, and the list moves on to the
-        // buffer the next step will undo
-        int32_t *keep = v.overlay[v.cur_overlay] + (int64_t)e * v.N;
-        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keep[i] = list[i];
-        if (blockIdx.x == 0 && threadIdx.x == 0) v.overlay_count[v.cur_overlay][e] = n;
-        return;
-    }
-    const GMaps mp(v.envs[e].maps);   // by value: the fields stay in registers across the stores below
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int cell = list[i];
-        if (cell >= 0) mp.semantic_map[cell] = mp.background_map[cell];
-    }
-}
-
 __global__ __launch_bounds__(256) void k_label(View v, const int32_t *__restrict__ semantic,
                                                const float *__restrict__ unc,
                                                const float *__restrict__ maxp,
@@ -537,6 +513,20 @@ __global__ __launch_bounds__(kFoundThreads) void k_found(View v) {
         __syncthreads();
     }
     if (found) v.hdr[e].found = 1;
+    // goal_decay: the local map of the update box goes back to zero for the next step (a launch less
+    // than clearing it in front of the scatter)
+    if (v.rule == SSMAP_RULE_GOAL_DECAY && v.local_clean) {
+        int r0, c0, bh, bw;
+        if (gd_box(v.hdr + e, r0, c0, bh, bw)) {
+            uint8_t *local = v.local_ids + (int64_t)e * v.local_stride;
+            const int64_t n = (int64_t)bh * bw;
+            // (four bytes a thread where the box allows; the buffer is 256-byte aligned per env)
+            for (int64_t i = 4 * (int64_t)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += 4 * (int64_t)gridDim.x * blockDim.x) {
+                if (i + 4 <= n) *reinterpret_cast<uint32_t *>(local + i) = 0u;
+                else for (int64_t k = i; k < n; ++k) local[k] = 0;
+            }
+        }
+    }
     // clear the wrapped-cell quadrant slots of this frame
     if (blockIdx.x == 0 && v.hdr[e].n_neg) {
         const unsigned n = v.hdr[e].n_winners;
@@ -551,14 +541,14 @@ void launch_label_rules(const View &v, const ssmap_frames &f, hipStream_t s) {
     dim3 grid(kListBlocks, v.E), block(256);
     if (v.rule == SSMAP_RULE_GOAL_DECAY) {
         const int erode = (int)ceil(0.1 / v.p2m), dil = (int)ceil(0.2 / v.p2m);
-        hipLaunchKernelGGL(k_gd_clear, grid, block, 0, s, v);
+        // (the engine's own scratch is zero between steps: the found kernel wipes what a step wrote)
+        if (!v.local_clean) hipLaunchKernelGGL(k_gd_clear, grid, block, 0, s, v);
         hipLaunchKernelGGL(k_gd_scatter, grid, block, 0, s, v, f.semantic, f.semantic_unc, f.semantic_gt);
         hipLaunchKernelGGL(k_gd_erode, grid, block, 0, s, v, erode);
         hipLaunchKernelGGL(k_gd_apply, grid, block, 0, s, v, dil);
         return;
     }
-    if (v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV)
-        hipLaunchKernelGGL(k_hv_revert, grid, block, 0, s, v);
+    // (hv rules: last frame's goal overlay was undone by the winner kernel)
     hipLaunchKernelGGL(k_label, grid, block, 0, s, v, f.semantic, f.semantic_unc, f.semantic_max_prob, f.semantic_gt);
 }
 

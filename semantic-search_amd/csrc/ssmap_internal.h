@@ -175,6 +175,7 @@ struct View {
     uint32_t *overlay_count[2];// [E]
     int32_t cur_overlay;       // which of the two lists is written this step
     int64_t local_stride;      // bytes per env in local_ids
+    int32_t local_clean;       // goal_decay: local_ids is zero between steps (the found kernel wipes what a step wrote)
     const int32_t *lut;        // [C] model class -> schema id
     const int32_t *pool_ids;   // [6][SSMAP_MAX_POOL]
     const int32_t *pool_count; // [6]

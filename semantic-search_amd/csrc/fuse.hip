@@ -659,6 +659,12 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
 }
 
 // ---------------------------------------------------------------- generic (LDS column) kernel
+// Class counts without a compiled register variant: a thread's classes live in a private LDS column
+// (stride 257 floats: conflict-free both down a column and across the columns of a wave).  The
+// arithmetic is the register kernel's (scaled logits differenced against their maximum, base-2
+// exponential and logarithm, arg-max from the tagged differences, entropy from the unnormalised
+// exponentials), so both paths round alike.  Owners' rows leave through their wave: the lanes read
+// the owner's column across the classes and write the row in one piece.
 template <int MODE>
 __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
     extern __shared__ float tile[];   // [C][kStride]
@@ -671,63 +677,81 @@ __global__ __launch_bounds__(kTile) void k_stream_lds(View v, StreamArgs a) {
     const int64_t fbase = (int64_t)e * v.N;
     const float *src = a.in + ((int64_t)e * C) * v.N + (active ? pix : 0);
     float *col = tile + t;
+    const float pre = a.from_logits ? a.inv_t : 1.0f;   // (x * 1.0f is x)
 
+    float m = -INFINITY;
     for (int c0 = 0; c0 < C; c0 += 8) {   // 8 loads in flight per thread
         float tmp[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) tmp[j] = (c0 + j < C) ? src[(int64_t)(c0 + j) * v.N] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (c0 + j < C) col[(c0 + j) * kStride] = tmp[j];
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < C) {
+                const float y = tmp[j] * pre;
+                col[(c0 + j) * kStride] = y;
+                m = fmaxf(m, y);
+            }
     }
+    float row_scale = 1.0f;   // what turns the column into probabilities
     if (a.from_logits) {
-        float m = -INFINITY;
-        for (int c = 0; c < C; ++c) {
-            const float xv = col[c * kStride] * a.inv_t;
-            col[c * kStride] = xv;
-            m = fmaxf(m, xv);
-        }
+#pragma clang fp contract(off)
         float s = 0.0f;
+        uint32_t key = 0xFFFFFFFFu;
         for (int c = 0; c < C; ++c) {
-            const float ev = expf(col[c * kStride] - m);
+            const float d = col[c * kStride] - m;
+            key = min(key, __builtin_bit_cast(uint32_t, d) | (uint32_t)c);
+            const float ev = __builtin_amdgcn_exp2f(d * 1.44269504088896341f);
             col[c * kStride] = ev;
             s += ev;
         }
-        float hsum = 0.0f, best = -1.0f;
-        int bi = 0;
         const float inv_s = 1.0f / s;
-        for (int c = 0; c < C; ++c) {
-            const float p = col[c * kStride] * inv_s;
-            col[c * kStride] = p;
-            hsum += p * logf(p + 1e-6f);
-            if (p > best) { best = p; bi = c; }
+        const int bi = (key >> 31) ? 0 : min((int)(key & 0xFFu), C - 1);
+        const float eps_s = 1e-6f * s;
+        float hsum = 0.0f;
+        for (int c = C - 1; c >= 0; --c) {
+            const float ev = col[c * kStride];
+            hsum = __builtin_fmaf(ev, __builtin_amdgcn_logf(ev + eps_s), hsum);
         }
+        const float h_bits = __builtin_amdgcn_logf(s) - hsum * inv_s;
         const int sid = v.lut[bi];
-        float conf = best;
+        float conf = inv_s;
         if (!a.pool_trivial && sid >= 3 && sid <= 8) {
             const int g = sid - 3;
             const int n = v.pool_count[g];
             float acc = 0.0f;
             for (int k = 0; k < n; ++k) {
-                const float pv = col[v.pool_ids[g * SSMAP_MAX_POOL + k] * kStride];
+                const float pv = col[v.pool_ids[g * SSMAP_MAX_POOL + k] * kStride] * inv_s;
                 acc = k == 0 ? pv : acc + pv;
             }
             conf = acc;   // an empty list sums to 0 (infer.py:116)
         }
         if (active) {
             if (a.sem_out) a.sem_out[fbase + pix] = sid;
-            if (a.unc_out) a.unc_out[fbase + pix] = -hsum / logf((float)C);
+            if (a.unc_out) a.unc_out[fbase + pix] = h_bits * (0.693147180559945309f / logf((float)C));
             if (a.maxp_out) a.maxp_out[fbase + pix] = conf;
             if (a.probs_out) {
                 float *dst = a.probs_out + ((int64_t)e * C) * v.N + pix;
-                for (int c = 0; c < C; ++c) dst[(int64_t)c * v.N] = col[c * kStride];
+                for (int c = 0; c < C; ++c) dst[(int64_t)c * v.N] = col[c * kStride] * inv_s;
             }
         }
+        row_scale = inv_s;
     }
     if (MODE == 0) return;
     const int slot = (active && !v.poses[e].skip) ? v.target[fbase + pix] : -1;
-    if (slot >= 0) {
-        float *dst = v.wprob + (fbase + slot) * v.wprob_stride;
-        for (int c = 0; c < C; ++c) dst[c] = col[c * kStride];
+    unsigned long long owners = __ballot(slot >= 0);
+    if (owners == 0ull) return;
+    // (the wave's own LDS accesses are executed in order: what an owner wrote above is there)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int lane = t & 63, wave_col = t & ~63;
+    while (owners) {
+        const int src_lane = __ffsll((long long)owners) - 1;
+        owners &= owners - 1ull;
+        const int s_own = __shfl(slot, src_lane);
+        const float rs = __shfl(row_scale, src_lane);
+        float *dst = v.wprob + (fbase + s_own) * v.wprob_stride;
+        const float *ocol = tile + wave_col + src_lane;
+        for (int c = lane; c < C; c += 64) dst[c] = ocol[c * kStride] * rs;
     }
 }
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -282,6 +284,8 @@ class SemanticMapper:
         self._engine: Optional[_engine.MapEngine] = None
         self._engine_key = None
         self._host_cache: Dict[str, np.ndarray] = {}
+        self._stage: Dict[str, torch.Tensor] = {}
+        self.pinned_staging = os.environ.get("SSMAP_PINNED_STAGING", "1") != "0"
         self._bound = False
         self._schema_sent = False
         self.last_status = 0
@@ -359,7 +363,19 @@ class SemanticMapper:
             val = obs[key]
             if isinstance(val, torch.Tensor):
                 return val.detach().to(device=dev, dtype=_TORCH_DTYPES[dtype]).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(val, dtype=dtype)).to(dev)
+            arr = np.ascontiguousarray(val, dtype=dtype)
+            if self.pinned_staging and arr.nbytes >= (1 << 20):
+                # large host arrays (the class probabilities are 49 MB a frame at 40 classes) go through a
+                # page-locked buffer that is kept between frames: a threaded host copy, then one DMA at
+                # PCIe rate, instead of the driver's chunked copy out of pageable memory.  The buffer is
+                # free again when update_map returns (the step's results are read behind a stream sync).
+                buf = self._stage.get(key)
+                if buf is None or tuple(buf.shape) != arr.shape or buf.dtype != _TORCH_DTYPES[dtype]:
+                    buf = torch.empty(arr.shape, dtype=_TORCH_DTYPES[dtype], pin_memory=True)
+                    self._stage[key] = buf
+                buf.copy_(torch.from_numpy(arr))
+                return buf.to(dev, non_blocking=True)
+            return torch.from_numpy(arr).to(dev)
 
         tens = {"depth": up("depth", np.float32)}
         if self.probablistic_mapping:

@@ -433,6 +433,23 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     constexpr bool NORM = MODE == 1 || MODE == 2;     // staged rows: the owners write probabilities
     constexpr int kLutRegs = (CT + 63) / 64;
     int lut_reg[kLutRegs];
+    int cellw = -1, pal_reg = 0, slot = -1;
+    float x[CT];
+    // The per-pixel word first (the owners' map rows are requested as soon as it is there), then the
+    // class planes, then the small tables: nothing that hangs on a chain of scalar loads (the skipped
+    // flag of the env's pose) stands between the block's start and its plane loads.
+    if (DIRECT) {
+        const __amdgpu_buffer_rsrc_t cells = __builtin_amdgcn_make_buffer_rsrc(v.ocell + fbase, 0, v.N * 4, 0x00020000);
+        cellw = __builtin_amdgcn_raw_buffer_load_b32(cells, active ? boff : -1, 0, 2 /* nt */);
+    }
+    if (MODE != 0 && !DIRECT) {
+        const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc(v.target + fbase, 0, v.N * 4, 0x00020000);
+        slot = __builtin_amdgcn_raw_buffer_load_b32(slots, active ? boff : -1, 0, 2 /* nt */);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+        x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+    __builtin_amdgcn_sched_barrier(0);
     if (a.from_logits || DIRECT) {
 #pragma unroll
         for (int k = 0; k < kLutRegs; ++k) {
@@ -440,34 +457,13 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
             lut_reg[k] = v.lut[idx < CT ? idx : 0];
         }
     }
-    // DIRECT: the map cell this pixel owns (-1: none) and, like the class table, the colour table
-    // spread over the lanes; both asked for in front of the class planes, so that the owners'
-    // map rows can be requested while the planes are still on their way
-    int cellw = -1, pal_reg = 0;
     if (DIRECT) {
-        const __amdgpu_buffer_rsrc_t cells = __builtin_amdgcn_make_buffer_rsrc(v.ocell + fbase, 0, v.N * 4, 0x00020000);
-        cellw = __builtin_amdgcn_raw_buffer_load_b32(cells, active ? boff : -1, 0, 2 /* nt */);
-        // (an env without a frame in this batch keeps last step's cell words: it owns nothing now)
-        if (!active || v.poses[e].skip) cellw = -1;
         const int row = (t & 63) < v.palette_rows ? (t & 63) : 0;
         const uint8_t *rgb = v.palette + 3 * row;
         pal_reg = (int)rgb[0] | ((int)rgb[1] << 8) | ((int)rgb[2] << 16);
     }
-    // staged rows: the pixel's slot in the frame's update list (-1: it owns no cell), asked for in
-    // front of the class planes like the cell word, so that no wave waits for a second memory round
-    // trip behind its C loads (at two waves per SIMD, 150 classes, that wait is a sixth of the
-    // wave's life)
-    int slot = -1;
-    if (MODE != 0 && !DIRECT) {
-        const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc(v.target + fbase, 0, v.N * 4, 0x00020000);
-        slot = __builtin_amdgcn_raw_buffer_load_b32(slots, active ? boff : -1, 0, 2 /* nt */);
-        // (an env without a frame in this batch keeps last step's slots: it stages nothing now)
-        if (!active || v.poses[e].skip) slot = -1;
-    }
-    float x[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-        x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frame, boff, c * plane_bytes, 2 /* nt */));
+    // (an env without a frame in this batch keeps last step's words: it owns and stages nothing now)
+    if (!active || v.poses[e].skip) { cellw = -1; slot = -1; }
     float row_scale = 1.0f;   // what turns x into probabilities (1 / sum while x holds the exponentials)
     DirectRows<DIRECT ? CT : 4> dr;
     __shared__ DirectShared dsh;

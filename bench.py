@@ -333,7 +333,11 @@ def dominant_kernel(workload, m):
     direct = prob_rule and C in (8, 40) and os.environ.get("SSMAP_DIRECT", "1") != "0"
     if direct:
         mode += 2
-        dom_bytes += state_b * E
+        # per update cell: the fused row read and written (2 * 4 C), label (4) and colour (3) written, and for
+        # the average family weight read and written (8) and uncertainty written (4); height map and
+        # ground-truth map of the cell are the winner kernel's
+        per_cell = 8 * C + 7 + (12 if "avg_prob" in wl["rule"] else 0)
+        dom_bytes += per_cell * m["k_mean"] * E
     # third template argument: how the pooled goal confidence is staged (0: every goal pools one
     # class, as the 40-class table does; 2: the SegFormer lists, known at compile time)
     reg = C in (8, 33, 37, 40, 53, 81, 150)

@@ -12,6 +12,13 @@
 #include <cstring>
 
 namespace ssmap {
+#ifdef SSMAP_TIMELINE
+// variant builds only: wall-clock stamps (10 ns ticks) of the winner kernel's phases, per block
+__device__ unsigned long long g_timeline[4096][12];
+#define SSMAP_STAMP(k) do { if (threadIdx.x == 0) g_timeline[blockIdx.y * gridDim.x + blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define SSMAP_STAMP(k) do { } while (0)
+#endif
 
 // Wave reductions of the geometry partials without LDS traffic: four DPP row rotations reduce
 // inside each 16-lane row, four lane reads combine the rows.  The cell box travels as two words
@@ -219,10 +226,6 @@ __device__ inline BinFrame bin_frame_box(const int32_t *box) {   // box = {rmin,
     // wide, at most 65 chunks of a row per table)
     f.per_row_magic = (1u << 20) / (unsigned)(f.per_row > 0 ? f.per_row : 1) + 1u;
     return f;
-}
-__device__ inline BinFrame bin_frame(const FrameHeader *hdr) {
-    const int32_t box[4] = {hdr->rmin, hdr->rmax, hdr->cmin, hdr->cmax};
-    return bin_frame_box(box);
 }
 __device__ inline int cell_slot(const BinFrame &f, uint32_t id) {
     const int row_b = (int)((id >> kCoordBits) & kCoordMask), col_b = (int)(id & kCoordMask);
@@ -434,9 +437,10 @@ __global__ __launch_bounds__(256) void k_geometry(View v, float *__restrict__ de
         for (int part = (int)(threadIdx.x >> 6); part < kBinParts; part += 4) {
             if (lane < min(s_cnt[part], 64u)) {
                 const int64_t at = blk_base + (int64_t)((uint32_t)part * part_stride + lane);
-                v.rec_h[at] = s_h[part][lane];
-                v.rec_w[at] = s_w[part][lane];
-                if (!PACKED) v.rec_s[at] = s_s[PACKED ? 0 : part][lane];
+                // (nontemporal like the winner kernel's reads of them)
+                __builtin_nontemporal_store(s_h[part][lane], &v.rec_h[at]);
+                __builtin_nontemporal_store(s_w[part][lane], &v.rec_w[at]);
+                if (!PACKED) __builtin_nontemporal_store(s_s[PACKED ? 0 : part][lane], &v.rec_s[at]);
             }
         }
     }
@@ -577,7 +581,7 @@ __device__ inline Rec<false> load_rec<false>(const View &v, int64_t at) {
 template <bool RUNS, bool PACKED>
 __device__ __forceinline__ void winners_body(const View &v, const float *__restrict__ depth_all, int write_target,
                                              int write_list, WinnerShared &sh, const WinnerPre &pre,
-                                             const int32_t *__restrict__ gt_all, bool commit_now) {
+                                             const int32_t *__restrict__ gt_all, bool commit_now, bool want_box) {
     unsigned long long (&table_h)[kSlots] = sh.table_h;
     unsigned int (&table_i)[kSlots] = sh.table_i;
     unsigned int &s_base = sh.s_base, &s_neg = sh.s_neg;
@@ -625,12 +629,15 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
     }
 
+    // the slot layout of the binned tables, from the header's box (already in registers)
+    const int32_t pre_box[4] = {pre.rmin, pre.rmax, pre.cmin, pre.cmax};
+    const BinFrame bf = bin_frame_box(pre_box);
     int inv_part = -1, inv_slot = 0;
     if (inv_L >= 0) {
         if (RUNS) {
             const uint32_t id = ((uint32_t)((int)(inv_L / bw) + rmin_b) << kCoordBits) | (uint32_t)((int)(inv_L % bw) + cmin_b);
             inv_part = cell_table(id);
-            inv_slot = cell_slot(bin_frame(hdr), id);
+            inv_slot = cell_slot(bf, id);
         } else {
             inv_part = (int)(inv_L >> kSlotShift);
             inv_slot = (int)(inv_L & (kSlots - 1));
@@ -686,6 +693,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         if (own_inv && threadIdx.x == 0) table_h[inv_slot] = inv_key;
         __syncthreads();
 
+        SSMAP_STAMP(3);
         // phase a
         if (RUNS) {
             {
@@ -698,9 +706,13 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
                 for (int u = 0; u < kKeep; ++u) {
                     const unsigned c = __builtin_amdgcn_readlane(cvec, u);
                     if ((unsigned)lane_id < c) {   // the block's first 64 records
-                        keep[u].h = hrow[lane_off + (unsigned)(u * kWaves * 64)];
-                        keep[u].w = wrow[lane_off + (unsigned)(u * kWaves * 64)];
-                        if constexpr (!PACKED) keep[u].s = srow[lane_off + (unsigned)(u * kWaves * 64)];
+                        // records are written once and read once: nontemporal on both sides keeps
+                        // them from displacing what the streaming kernel will find in the caches
+                        // (the winner kernel itself reads 1.6 us slower for it, the streaming kernel
+                        // 3.5 us faster at 40 classes, 13 us at 150)
+                        keep[u].h = __builtin_nontemporal_load(&hrow[lane_off + (unsigned)(u * kWaves * 64)]);
+                        keep[u].w = __builtin_nontemporal_load(&wrow[lane_off + (unsigned)(u * kWaves * 64)]);
+                        if constexpr (!PACKED) keep[u].s = __builtin_nontemporal_load(&srow[lane_off + (unsigned)(u * kWaves * 64)]);
                     }
                 }
             }
@@ -726,6 +738,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
         }
         __syncthreads();
+        SSMAP_STAMP(4);
         // phase b
         if (own_inv && threadIdx.x == 0) {
             const int s = inv_slot;
@@ -757,6 +770,7 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
         }
         }
         __syncthreads();
+        SSMAP_STAMP(5);
         // phase c: emit the surviving slots in slot order (= row-major cell order), so that
         // neighbouring list entries are neighbouring map cells.  The surviving slots (an eighth of the
         // table on a typical frame) are first compacted in LDS, so that the emission proper runs with
@@ -801,66 +815,98 @@ __device__ __forceinline__ void winners_body(const View &v, const float *__restr
                 sh.comp[s_cnt[it * kWaves + wave] + (unsigned)__popcll(balls[it] & ((1ull << lane) - 1ull))] =
                     (unsigned short)(it * kWinnerThreads + threadIdx.x);
         __syncthreads();
+        SSMAP_STAMP(6);
         unsigned n_neg = 0;
         const unsigned total = write_list ? sh.s_total : 0u;
-        // the slot layout once for the whole emission
-        const BinFrame bf = bin_frame(hdr);
-        for (unsigned j = threadIdx.x; j < total; j += kWinnerThreads) {
-            const int s = (int)sh.comp[j];
-            const int pix = (int)(table_i[s] >> 1);
-            const unsigned long long hk = table_h[s];
-            int row, col;
-            if (RUNS) {
-                slot_cell(bf, p, s, row, col);
-            } else {
-                // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
-                const unsigned L = ((unsigned)p << kSlotShift) + (unsigned)s;
-                const unsigned lrow = L / (unsigned)bw;
-                row = (int)lrow + rmin;
-                col = (int)(L - lrow * (unsigned)bw) + cmin;
+        // Two list entries per thread and trip (the tables of a typical frame hold a few more than
+        // kWinnerThreads survivors each): the loads of both entries are issued before the first store,
+        // so a trip costs one round trip to memory, not one per entry.  A lane without a second entry
+        // repeats its first one's addresses for the loads and stores nothing for it.
+        constexpr int kPer = 2;
+        for (unsigned j0 = threadIdx.x; j0 < total; j0 += kPer * kWinnerThreads) {
+            bool on[kPer];
+            int cellv[kPer], pixv[kPer], gv[kPer];
+            uint32_t wordv[kPer];
+            unsigned long long hkv[kPer];
+            float ho[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const unsigned j = j0 + (unsigned)(k * kWinnerThreads);
+                on[k] = j < total;
+                const int s = (int)sh.comp[on[k] ? j : j0];
+                pixv[k] = (int)(table_i[s] >> 1);
+                hkv[k] = table_h[s];
+                int row, col;
+                if (RUNS) {
+                    slot_cell(bf, p, s, row, col);
+                } else {
+                    // cell numbers fit 32 bits (a box holds at most 4 * 8192^2 = 2^28 cells)
+                    const unsigned L = ((unsigned)p << kSlotShift) + (unsigned)s;
+                    const unsigned lrow = L / (unsigned)bw;
+                    row = (int)lrow + rmin;
+                    col = (int)(L - lrow * (unsigned)bw) + cmin;
+                }
+                if (want_box && on[k]) {
+                    lrmin = min(lrmin, row); lrmax = max(lrmax, row);
+                    lcmin = min(lcmin, col); lcmax = max(lcmax, col);
+                }
+                // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
+                const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
+                cellv[k] = wr * Wm + wc;
+                n_neg += (on[k] && (row < 0 || col < 0)) ? 1u : 0u;
+                wordv[k] = (uint32_t)pixv[k] | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
+                ho[k] = 0.0f;
+                gv[k] = 0;
+                if (commit) {
+                    ho[k] = pre.height_map[cellv[k]];
+                    if (gt_all) gv[k] = gt_all[fbase + pixv[k]];
+                }
             }
-            lrmin = min(lrmin, row); lrmax = max(lrmax, row);
-            lcmin = min(lcmin, col); lcmax = max(lcmax, col);
-            // numpy index wrap for -dim <= idx < 0 (mapper.py:326-338 masks only the upper bound)
-            const int wr = row < 0 ? row + Hm : row, wc = col < 0 ? col + Wm : col;
-            const int cell = wr * Wm + wc;
-            n_neg += (row < 0 || col < 0) ? 1u : 0u;
-            float ho = 0.0f;
-            int gv = 0;
-            if (commit) {
-                ho = pre.height_map[cell];
-                if (gt_all) gv = gt_all[fbase + pix];
-            }
-            const unsigned pos = s_base + j;
-            int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
-            const uint32_t word = (uint32_t)pix | (row < 0 ? kRowNegBit : 0u) | (col < 0 ? kColNegBit : 0u);
-            *out = make_int2((int)word, cell);
-            v.wheight[fbase + pos] = hk;
-            if (commit) {
-                const float hn = fmaxf(ho, (float)(unorder_f64(hk) - pre.agent_y));
-                pre.height_map[cell] = hn;
-                if (gt_all) pre.gt_map[cell] = (uint32_t)gv;
-                v.ocell[fbase + pix] = owner_word(cell, hn);
-            } else if (write_target == 2) {
-                // a frame whose list may still change (wrapped cells, an IndexError candidate): the
-                // frame's last block writes the maps and the height bits once the list stands
-                v.ocell[fbase + pix] = cell;
-            } else if (write_target) {
-                v.target[fbase + pix] = (int)pos;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                if (!on[k]) continue;
+                const unsigned pos = s_base + j0 + (unsigned)(k * kWinnerThreads);
+                const int cell = cellv[k], pix = pixv[k];
+                int2 *out = reinterpret_cast<int2 *>(v.winners) + fbase + pos;
+                if (write_target) {
+                    // probability rules: the streaming kernel runs before anything reads the list
+                    // again (nontemporal: 1 us per step); the label rules read it next (plain)
+                    typedef int int2v __attribute__((ext_vector_type(2)));
+                    int2v ev; ev.x = (int)wordv[k]; ev.y = cell;
+                    __builtin_nontemporal_store(ev, reinterpret_cast<int2v *>(out));
+                    __builtin_nontemporal_store(hkv[k], &v.wheight[fbase + pos]);
+                } else {
+                    *out = make_int2((int)wordv[k], cell);
+                    v.wheight[fbase + pos] = hkv[k];
+                }
+                if (commit) {
+                    const float hn = fmaxf(ho[k], (float)(unorder_f64(hkv[k]) - pre.agent_y));
+                    pre.height_map[cell] = hn;
+                    if (gt_all) pre.gt_map[cell] = (uint32_t)gv[k];
+                    v.ocell[fbase + pix] = owner_word(cell, hn);
+                } else if (write_target == 2) {
+                    // a frame whose list may still change (wrapped cells, an IndexError candidate): the
+                    // frame's last block writes the maps and the height bits once the list stands
+                    v.ocell[fbase + pix] = cell;
+                } else if (write_target) {
+                    v.target[fbase + pix] = (int)pos;
+                }
             }
         }
         if (n_neg) atomicAdd(&s_neg, n_neg);
         __syncthreads();
+        SSMAP_STAMP(7);
         if (!RUNS && p + (int)gridDim.x < nparts)
             for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { table_h[s] = 0ull; table_i[s] = kNoPixel; }
     }
 
-    // bbox of the update cells (goal_decay works on it, mapper.py:1117-1118)
-    lrmin = wave_min(lrmin); lrmax = wave_max(lrmax);
-    lcmin = wave_min(lcmin); lcmax = wave_max(lcmax);
-    // one set of header atomics per block (same-line atomics serialise at the memory side)
     __syncthreads();
     if (threadIdx.x == 0 && s_neg) atomicAdd(&hdr->n_neg, s_neg);
+    if (!want_box) return;
+    // bbox of the update cells (goal_decay works on it, mapper.py:1117-1118): one set of header
+    // atomics per block (same-line atomics serialise at the memory side)
+    lrmin = wave_min(lrmin); lrmax = wave_max(lrmax);
+    lcmin = wave_min(lcmin); lcmax = wave_max(lcmax);
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
         s_box[w][0] = lrmin; s_box[w][1] = lrmax; s_box[w][2] = lcmin; s_box[w][3] = lcmax;
@@ -1089,12 +1135,13 @@ __device__ inline void hv_keep_overlay(const View &v, int e, unsigned first, uns
 // Every block of a frame sees the same box and reports, so they agree on whether tickets are taken.
 __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float *__restrict__ depth_all,
                                                             const int32_t *__restrict__ gt_all,
-                                                            int write_target, int write_list, int hv_rule) {
+                                                            int write_target, int write_list, int hv_rule, int want_box) {
     __shared__ WinnerShared sh;
     __shared__ unsigned int s_last;
     const int e = blockIdx.y;
     FrameHeader *hdr = v.hdr + e;
     const unsigned hv_first = blockIdx.x * kWinnerThreads + threadIdx.x, hv_stride = gridDim.x * kWinnerThreads;
+    SSMAP_STAMP(0);
     if (v.poses[e].skip) {   // no frame for this env (its header says zero update cells)
         if (hv_rule) hv_keep_overlay(v, e, hv_first, hv_stride, blockIdx.x == 0 && threadIdx.x == 0);
         return;
@@ -1119,7 +1166,9 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     }
     // clearing the tables overlaps with those loads
     for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { sh.table_h[s] = 0ull; sh.table_i[s] = kNoPixel; }
+    SSMAP_STAMP(1);
     fold_reports(rep, sh);
+    SSMAP_STAMP(2);
     // an index-error report of the geometry kernel is a candidate: the frame's last block decides
     const bool err_candidate = (sh.frame.err & SSMAP_ENV_INDEX_ERROR) != 0u;
     // (a frame that may still raise leaves last frame's overlay to its last block, which knows)
@@ -1134,9 +1183,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     // frame sees the same box and reports, so they agree on it)
     const bool deferred = may_wrap || err_candidate;
     if (sh.frame.spill || !bin_frame_box(box).on || v.geom_blocks > kMaxGeomBlocksBinned)
-        winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
-    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
-    else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred);
+        winners_body<false, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred, want_box != 0);
+    else if (v.rec_packed) winners_body<true, true>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred, want_box != 0);
+    else winners_body<true, false>(v, depth_all, write_target, write_list, sh, pre, gt_all, !deferred, want_box != 0);
+    SSMAP_STAMP(8);
     if (!deferred) return;
     __syncthreads();   // every thread's list entries and the block's header atomics are issued
     if (threadIdx.x == 0) {
@@ -1187,7 +1237,14 @@ void launch_winners(const View &v, const ssmap_frames &f, hipStream_t s) {
     const bool prob_rule = v.rule >= SSMAP_RULE_AVG_PROB && v.rule <= SSMAP_RULE_LOG_ODDS;
     dim3 grid(kWinnerPartsPerEnv, v.E);
     const int hv_rule = (v.rule == SSMAP_RULE_HV || v.rule == SSMAP_RULE_PROB_HV) ? 1 : 0;
-    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, f.semantic_gt, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1, hv_rule);
+    hipLaunchKernelGGL(k_winners, grid, dim3(kWinnerThreads), 0, s, v, f.depth, f.semantic_gt, prob_rule ? (v.direct_update ? 2 : 1) : 0, 1, hv_rule,
+                       v.rule == SSMAP_RULE_GOAL_DECAY ? 1 : 0);
 }
 
 }  // namespace ssmap
+#ifdef SSMAP_TIMELINE
+extern "C" int ssmap_debug_timeline(unsigned long long *out, int blocks) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssmap::g_timeline), (size_t)blocks * 12 * 8);
+}
+#endif

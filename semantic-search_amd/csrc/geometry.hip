@@ -1143,11 +1143,9 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
     FrameHeader *hdr = v.hdr + e;
     const unsigned hv_first = blockIdx.x * kWinnerThreads + threadIdx.x, hv_stride = gridDim.x * kWinnerThreads;
     SSMAP_STAMP(0);
-    if (v.poses[e].skip) {   // no frame for this env (its header says zero update cells)
-        if (hv_rule) hv_keep_overlay(v, e, hv_first, hv_stride, blockIdx.x == 0 && threadIdx.x == 0);
-        return;
-    }
-    // every first load of the block in one group: the latencies overlap instead of adding up
+    // every first load of the block in one group, the env's skipped flag among them: the latencies
+    // overlap instead of adding up (a skipped env's reports are stale, and unused)
+    const int skip = v.poses[e].skip;
     const ReportRegs rep = load_reports(v, e);
     WinnerPre pre;
     {
@@ -1164,6 +1162,10 @@ __global__ __launch_bounds__(kWinnerThreads) void k_winners(View v, const float 
         const int b = (int)(threadIdx.x >> 6) + (kWinnerThreads / 64) * (int)(threadIdx.x & 63);
         pre.cnt = (v.geom_blocks <= kMaxGeomBlocksBinned && b < v.geom_blocks)
                       ? v.bin_cnt[((int64_t)e * kMaxParts + blockIdx.x) * v.geom_blocks + b] : 0u;
+    }
+    if (skip) {   // no frame for this env (its header says zero update cells)
+        if (hv_rule) hv_keep_overlay(v, e, hv_first, hv_stride, blockIdx.x == 0 && threadIdx.x == 0);
+        return;
     }
     // clearing the tables overlaps with those loads
     for (int s = threadIdx.x; s < kSlots; s += kWinnerThreads) { sh.table_h[s] = 0ull; sh.table_i[s] = kNoPixel; }

@@ -145,7 +145,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + d * wgt;
                     sm += mv[k][j];
                 }
-                store_row(mrow + c, mv[k], THROUGH);
+                if (!(v.exp & 32)) store_row(mrow + c, mv[k], THROUGH);
             }
         }
         sm = row_sum(sm);
@@ -180,7 +180,7 @@ __device__ __forceinline__ void update_row(const View &v, int C, float log2_c, b
                     mv[k][j] = mv[k][j] + log_hw(q);
                     { const bool take = arg_better(mv[k][j], c + j, best, bi); best = take ? mv[k][j] : best; bi = take ? c + j : bi; }
                 }
-                store_row(mrow + c, mv[k], THROUGH);
+                if (!(v.exp & 32)) store_row(mrow + c, mv[k], THROUGH);
             }
         }
     }
@@ -239,7 +239,7 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
     // the cell's scalars leave through two store instructions: lanes 1, 2 and 4 of the row write one
     // 32-bit map each, lanes 5..7 the colour bytes (after the row reductions every lane of the
     // row holds the same values)
-    if (on) {
+    if (on && !(v.exp & 16)) {
         gptr<int> dst = nullptr;
         int val = 0;
         if (sub == 1 && UMODE == 1) { dst = (gptr<int>)(m.weight + cell); val = __builtin_bit_cast(int, wn); }

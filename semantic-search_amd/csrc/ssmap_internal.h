@@ -196,7 +196,11 @@ struct View {
     const int32_t *disk_hw;    // [radius+1] half-widths of the found disk
     int32_t disk_radius;
     ssmap_params prm;
-    int32_t exp, exp_lds;      // measurement knobs (SSMAP_EXP, SSMAP_EXP_LDS)
+    // measurement knobs (SSMAP_EXP, SSMAP_EXP_LDS in the environment; wrong results, safe addresses): parts
+    // of the direct update switched off, to see what each costs.  1 nothing after the row requests,
+    // 2 nothing after the owners have parked their rows, 4 all arithmetic but no stores, 8 every row of
+    // cell 0, 16 no label / colour / weight stores, 32 no map-row stores
+    int32_t exp, exp_lds;
 };
 
 __host__ __device__ inline unsigned long long order_f64(double h) {

@@ -286,6 +286,7 @@ class SemanticMapper:
         self._host_cache: Dict[str, np.ndarray] = {}
         self._stage: Dict[str, torch.Tensor] = {}
         self.pinned_staging = os.environ.get("SSMAP_PINNED_STAGING", "1") != "0"
+        self.staging_chunks = int(os.environ.get("SSMAP_STAGING_CHUNKS", "4"))
         self._bound = False
         self._schema_sent = False
         self.last_status = 0
@@ -373,8 +374,20 @@ class SemanticMapper:
                 if buf is None or tuple(buf.shape) != arr.shape or buf.dtype != _TORCH_DTYPES[dtype]:
                     buf = torch.empty(arr.shape, dtype=_TORCH_DTYPES[dtype], pin_memory=True)
                     self._stage[key] = buf
-                buf.copy_(torch.from_numpy(arr))
-                return buf.to(dev, non_blocking=True)
+                src = torch.from_numpy(arr)
+                if arr.nbytes < (8 << 20) or self.staging_chunks <= 1:
+                    buf.copy_(src)
+                    return buf.to(dev, non_blocking=True)
+                # the largest arrays in pieces: the DMA of one piece runs while the host copies the next
+                out = torch.empty(arr.shape, dtype=_TORCH_DTYPES[dtype], device=dev)
+                fb, fs, fo = buf.view(-1), src.view(-1), out.view(-1)
+                n = fb.numel()
+                step = -(-n // self.staging_chunks)
+                for lo in range(0, n, step):
+                    hi = min(lo + step, n)
+                    fb[lo:hi].copy_(fs[lo:hi])
+                    fo[lo:hi].copy_(fb[lo:hi], non_blocking=True)
+                return out
             return torch.from_numpy(arr).to(dev)
 
         tens = {"depth": up("depth", np.float32)}

@@ -808,6 +808,38 @@ def test_update_map_takes_torch_tensors_like_numpy_arrays():
         assert np.array_equal(getattr(mappers[0], name), getattr(mappers[1], name), equal_nan=True), name
 
 
+def test_host_arrays_staged_whole_in_pieces_or_pageable_give_the_same_maps():
+    """A full-size frame (49 MB of class probabilities) fed as numpy arrays: the page-locked staging
+    buffer filled in one piece, in overlapped pieces (the default) and plain pageable copies end in
+    the same maps, over two frames (the second reuses the staging buffers)."""
+    import semantic_search_amd as ssa
+    c = 40
+    lut = scenes.schema_lut(c)
+    kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
+              prob_aggregate="height_map_avg_prob", seg_model_n_classes=c)
+    bounds = np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5])
+    mappers = []
+    for pinned, chunks in ((True, 1), (True, 4), (True, 7), (False, 1)):
+        m = ssa.SemanticMapper(**kw)
+        m.map_seg_to_schema = lambda ids: lut[ids]
+        m.pinned_staging, m.staging_chunks = pinned, chunks
+        m.reset(bounds)
+        mappers.append(m)
+    rng = np.random.default_rng(17)
+    for i in range(2):
+        agent, cam = scenes.make_pose(1.5 + 0.3 * i, 0.0, 1.2, 0.8 - 0.3 * i)
+        frame = scenes.room_frame(rng, 480, 640, c, 1.0, cam, lut=lut)
+        outs = [m.update_map(scenes.make_obs(frame, agent, cam, goal_index=0)) for m in mappers]
+        for ego, found in outs[1:]:
+            assert found == outs[0][1]
+            for a, b in zip(ego, outs[0][0]):
+                assert np.array_equal(a, b)
+    assert mappers[0].semantic_map.any()
+    for m in mappers[1:]:
+        for name in ("semantic_map", "height_map", "gt_map", "avg_prob_seg_map", "avg_prob_weight_map", "unc_map"):
+            assert np.array_equal(getattr(m, name), getattr(mappers[0], name), equal_nan=True), name
+
+
 @pytest.mark.parametrize("rule", ["height_map_log_odds", "height_map_prob_hv", "height_map_goal_decay"])
 def test_mapper_episodes_with_different_map_bounds(rule):
     """One SemanticMapper over three episodes, like an env that resets it per scene (env.py:377):

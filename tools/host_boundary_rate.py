@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--classes", type=int, default=40)
     ap.add_argument("--rule", default="height_map_log_odds")
+    ap.add_argument("--chunks", type=int, default=4, help="pieces the largest arrays are staged in (1: whole)")
     ap.add_argument("--pinned", type=int, default=1, help="0: pageable copies, as the driver makes them; 1: the shim's page-locked staging buffers")
     args = ap.parse_args()
     import torch
@@ -31,6 +32,7 @@ def main():
                            probablistic_mapping=True, prob_aggregate=args.rule, seg_model_n_classes=C)
     m.map_seg_to_schema = lambda ids: lut[ids]
     m.pinned_staging = bool(args.pinned)
+    m.staging_chunks = args.chunks
     m.reset(np.array([0.0, -0.2, 0.0, 4.5, 2.5, 4.5]))
     frames = []
     for i in range(4):
@@ -48,7 +50,7 @@ def main():
     dt = time.perf_counter() - t0
     nbytes = sum(np.asarray(v).nbytes for v in frames[0].values() if isinstance(v, np.ndarray))
     print(json.dumps({"what": "SemanticMapper.update_map fed numpy observations (1 env)", "rule": args.rule,
-                      "classes": C, "pinned_staging": bool(args.pinned), "frames": args.frames, "frames_per_s": args.frames / dt,
+                      "classes": C, "pinned_staging": bool(args.pinned), "chunks": args.chunks, "frames": args.frames, "frames_per_s": args.frames / dt,
                       "ms_per_frame": 1e3 * dt / args.frames, "host_bytes_per_frame": nbytes}))
 
 

@@ -34,6 +34,9 @@ namespace ssmap {
 #ifndef SSMAP_WPE0MAX
 #define SSMAP_WPE0MAX 3
 #endif
+#ifndef SSMAP_WPEDMAX
+#define SSMAP_WPEDMAX 8
+#endif
 #ifndef SSMAP_WPED
 #define SSMAP_WPED 1
 #endif
@@ -253,16 +256,17 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
 // ---------------------------------------------------------------- direct update (narrow rows)
 // The streaming kernel updates the map cells its pixels own by itself: no probability rows leave
 // the kernel and no update kernel runs.  Per wave:
-//   request  as soon as the per-pixel cell words are there (the class planes are still in flight):
-//            the owners' cells are exchanged through LDS, then every 16-lane row asks for one
-//            owner's map row (a vector per lane) and its scalars (height, weight, ground truth,
-//            new height; lanes 0..3 of the row), for the first kDirectPre owners of the wave;
-//   update   after the softmax: the owners park their probabilities in the wave's LDS rows, every
-//            16-lane row updates its cell exactly as k_update_prob does (update_row) and writes the
-//            map row and the cell's scalars.  Owners beyond kDirectPre (rare) follow in further
-//            passes that load at that point.
-// All of it is local to the wave (no block barrier).  The streaming kernel runs as fast at half
-// its occupancy, so the longer life of its waves (a second memory round trip) costs nothing.
+//   request  as soon as the per-pixel words are there (the class planes are still in flight): the
+//            owners' words (cell + the two height bits the winner kernel left) are exchanged through
+//            LDS, the block's owners pooled, then every 16-lane row asks for one owner's map row (a
+//            class per lane and step) and, for the average family, the cell's weight, for the first
+//            kDirectPre owners of the block;
+//   update   after the softmax: the owners park their exponentials (and their scale) in the block's
+//            LDS rows, every 16-lane row updates its cell exactly as k_update_prob does (update_row)
+//            and writes the map row, weight / entropy (average family), label and colour.  Height
+//            map and ground-truth map are the winner kernel's.  Owners beyond kDirectPre (rare)
+//            follow in further passes that load at that point.
+// Two block barriers in the request, one per pass in the update.
 constexpr int kDirectPre = 32;   // owners per block (and pass) whose map rows are requested ahead
 struct DirectShared {
     int count[kRegTile / 64];
@@ -413,7 +417,7 @@ struct DirectRows {
 // wider loads measured slower: the larger register footprint costs more occupancy than the
 // wider requests gain.)
 template <int CT, int MODE, int POOL>
-__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? SSMAP_WPE150 : (MODE >= 3 ? SSMAP_WPED : SSMAP_WPE0), CT > 128 ? SSMAP_WPE150 : (MODE == 0 ? SSMAP_WPE0MAX : 8)))) void k_stream_reg(View v, StreamArgs a) {
+__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? SSMAP_WPE150 : (MODE >= 3 ? SSMAP_WPED : SSMAP_WPE0), CT > 128 ? SSMAP_WPE150 : (MODE == 0 ? SSMAP_WPE0MAX : (MODE >= 3 ? SSMAP_WPEDMAX : 8))))) void k_stream_reg(View v, StreamArgs a) {
     extern __shared__ float s_pool[];   // POOL: [pool_slots][kRegTile], a column per thread
     const int e = blockIdx.y;
     const int t = threadIdx.x;

@@ -328,9 +328,9 @@ def dominant_kernel(workload, m):
     geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, m["k_mean"], prob_rule)
     dom_bytes = s1_b * E
     mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
-    # narrow class counts: the streaming kernel also updates the owners' map cells (modes 3, 4),
+    # 8, 40 and 150 classes: the streaming kernel also updates the owners' map cells (modes 3, 4),
     # so its compulsory bytes include the state traffic and no update kernel runs
-    direct = prob_rule and C in (8, 40) and os.environ.get("SSMAP_DIRECT", "1") != "0"
+    direct = prob_rule and C in (8, 40, 150) and os.environ.get("SSMAP_DIRECT", "1") != "0"
     if direct:
         mode += 2
         # per update cell: the fused row read and written (2 * 4 C), label (4) and colour (3) written, and for

@@ -128,7 +128,7 @@ size_t carve_step_scratch(const ssmap_config &c, View &v, unsigned char *base) {
     take(v.rec_s, packed ? 0 : n_rec);
     const bool direct = prob_rule && v.direct_update;
     take(v.target, prob_rule && !direct ? EN : 0);
-    take(v.wprob, prob_rule && !direct ? EN * (size_t)c.n_classes : 0);
+    take(v.wprob, prob_rule && !direct ? EN * (size_t)(v.wprob_stride > c.n_classes ? v.wprob_stride : c.n_classes) : 0);
     take(v.ocell, direct ? EN : 0);
     take(v.winners, EN * 2);
     take(v.wheight, EN);
@@ -290,6 +290,7 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.geom_blocks = (v.N + kGeomPixPerBlock - 1) / kGeomPixPerBlock;
     v.rec_packed = v.N <= (1 << kPackPixBits) ? 1 : 0;
     v.wprob_stride = v.C;   // padding the rows (to 16 bytes, to whole cache lines) measured slower
+    if (const char *x = getenv("SSMAP_WPROB_STRIDE")) v.wprob_stride = atoi(x) > v.C ? atoi(x) : v.C;
     // Class counts with a direct variant of the register streaming kernel: it updates the owners'
     // map cells itself; the others go through staged rows and the update kernel.
     v.direct_update = (prob_rule && direct_class_count(v.C) && (int64_t)v.C * v.N * 4 < (1ll << 31) &&

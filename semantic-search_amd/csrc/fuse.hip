@@ -218,7 +218,7 @@ struct DirectMaps {
 // row (lane `sub` holds the classes sub + 16k), cellw = the owner's word (the cell, and what the
 // occupancy override asks of the cell's new height: the winner kernel has raised the height map
 // and written the ground-truth map already).  update_row, then label and colour.
-template <int UMODE, int CT, int K, typename VecF>
+template <int UMODE, int CT, int V, int K, typename VecF>
 __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, float log2_c, bool on, int lane, int cellw,
                                             float w_old, const VecF (&p)[K], VecF (&mv)[K],
                                             const int (&lut_reg)[(CT + 63) / 64], int pal_reg) {
@@ -227,7 +227,7 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
     const gptr<float> mrow = m.prob + (int64_t)cell * CT;
     int bi;
     float wn, ent_out;
-    update_row<UMODE, 1, K>(v, CT, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
+    update_row<UMODE, V, K>(v, CT, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
     int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
 #pragma unroll
     for (int k = 1; k < (CT + 63) / 64; ++k) {
@@ -253,7 +253,7 @@ __device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, 
     }
 }
 
-// ---------------------------------------------------------------- direct update (narrow rows)
+// ---------------------------------------------------------------- direct update
 // The streaming kernel updates the map cells its pixels own by itself: no probability rows leave
 // the kernel and no update kernel runs.  Per wave:
 //   request  as soon as the per-pixel words are there (the class planes are still in flight): the
@@ -280,9 +280,14 @@ struct DirectRows {
     // are pooled: batches of four cells are dealt to the block's waves in turn, so that the rows of
     // a batch are full (a typical block of 256 pixels owns 14 cells: four batches, one per wave,
     // where the waves on their own would run five or six)
-    static constexpr int V = 1, K = (CT + 15) / 16, NB = kDirectPre / 4 / (kRegTile / 64);
+#ifndef SSMAP_DIRECT_WIDE_V
+#define SSMAP_DIRECT_WIDE_V 2
+#endif
+    // (wide rows: two classes per lane and step, half the load and store instructions per cell)
+    static constexpr int V = (CT > 64 && CT % SSMAP_DIRECT_WIDE_V == 0) ? SSMAP_DIRECT_WIDE_V : 1;
+    static constexpr int K = (CT + 16 * V - 1) / (16 * V), NB = kDirectPre / 4 / (kRegTile / 64);
     static constexpr int SV = CT % 4 == 0 ? 4 : (CT % 2 == 0 ? 2 : 1);   // widest vector an owner parks its row with
-    typedef float VecF __attribute__((ext_vector_type(1)));
+    typedef float VecF __attribute__((ext_vector_type(V)));
     typedef float VecS __attribute__((ext_vector_type(SV)));
     VecF mv[NB][K];
     float w_old[NB];      // average family: the cell's weight so far
@@ -400,7 +405,7 @@ struct DirectRows {
                         mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
                     }
                 }
-                direct_cell<UMODE, CT, K>(v, maps, log2_c, on[b], lane, cell[b], (UMODE == 1 && on[b]) ? w_old[b] : 0.0f,
+                direct_cell<UMODE, CT, V, K>(v, maps, log2_c, on[b], lane, cell[b], (UMODE == 1 && on[b]) ? w_old[b] : 0.0f,
                                           p, mv[b], lut_reg, pal_reg);
             }
             if (r0 + kDirectPre < n_blk) __syncthreads();   // another pass reuses the LDS rows (the same for the whole block)

@@ -940,9 +940,10 @@ def test_one_env_of_a_batch_is_reset_while_the_others_go_on(rule):
         s.close()
 
 
-@pytest.mark.parametrize("rule,c", [("height_map_log_odds", 40), ("height_map_w2_avg_prob", 40), ("height_map_avg_prob", 8)])
+@pytest.mark.parametrize("rule,c", [("height_map_log_odds", 40), ("height_map_w2_avg_prob", 40), ("height_map_avg_prob", 8),
+                                    ("height_map_w2_avg_prob", 150), ("height_map_log_odds", 150)])
 def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
-    """The two homes of the probability rules' update for 8 and 40 classes: inside the streaming kernel
+    """The two homes of the probability rules' update for 8, 40 and 150 classes: inside the streaming kernel
     (default) and as staged rows + k_update_prob (SSMAP_DIRECT=0 when the engine is created).  Same
     update_row; integer maps and the log-odds sums are bit-identical, the averages and their entropy
     weights agree to 1e-6 (the entropy sums run over another class-to-lane layout)."""

@@ -43,6 +43,9 @@ WORKLOADS = {
 H, W = 480, 640
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 # a class count none of the register streaming kernels is compiled for: the generic LDS-column path
+# other heads of the reference's EMSANet wrapper (infer.py: 37 classes SUNRGB-D; 81 as the widest of them)
+WORKLOADS["log_odds_c37"] = dict(rule="height_map_log_odds", C=37, T=3.2, span=14.39, attrs=dict(entropy_threshold=0.0171))
+WORKLOADS["w2_avg_prob_c81"] = dict(rule="height_map_w2_avg_prob", C=81, T=2.5, span=14.39, attrs=dict(entropy_threshold=0.4820))
 WORKLOADS["avg_prob_c21"] = dict(rule="height_map_avg_prob", C=21, T=3.2, span=14.39,
                                  attrs=dict(entropy_threshold=0.43759))
 
@@ -328,9 +331,9 @@ def dominant_kernel(workload, m):
     geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, m["k_mean"], prob_rule)
     dom_bytes = s1_b * E
     mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
-    # 8, 40 and 150 classes: the streaming kernel also updates the owners' map cells (modes 3, 4),
+    # class counts with a register kernel: the streaming kernel also updates the owners' map cells (modes 3, 4),
     # so its compulsory bytes include the state traffic and no update kernel runs
-    direct = prob_rule and C in (8, 40, 150) and os.environ.get("SSMAP_DIRECT", "1") != "0"
+    direct = prob_rule and C in (8, 33, 37, 40, 53, 81, 150) and os.environ.get("SSMAP_DIRECT", "1") != "0"
     if direct:
         mode += 2
         # per update cell: the fused row read and written (2 * 4 C), label (4) and colour (3) written, and for

@@ -130,11 +130,12 @@ struct EnvState {
 };
 
 // Class counts for which the register streaming kernel has a variant that updates the owners' map
-// cells itself (the EMSANet NYUv2 head, the SegFormer ADE20k head and the 8 classes of the tests).
+// cells itself: every count the register kernel is compiled for (the EMSANet heads, the SegFormer
+// ADE20k head and the 8 classes of the tests).
 // At 150 classes the kernel runs at two waves per SIMD and its tail is not hidden (200 us of 700 at
 // 16 envs), but staging the rows costs more: 100 us for their scattered stores beside the streaming
 // reads and 127 us for the update kernel that reads them back from cold caches.
-constexpr bool direct_class_count(int c) { return c == 8 || c == 40 || c == 150; }
+constexpr bool direct_class_count(int c) { return c == 8 || c == 33 || c == 37 || c == 40 || c == 53 || c == 81 || c == 150; }
 
 // Everything a kernel needs, passed by value.
 struct View {

@@ -331,9 +331,10 @@ def dominant_kernel(workload, m):
     geo_b, s1_b, state_b = algorithmic_bytes_per_frame(C, m["k_mean"], prob_rule)
     dom_bytes = s1_b * E
     mode = (2 if "log_odds" in wl["rule"] else 1) if prob_rule else 0
-    # class counts with a register kernel: the streaming kernel also updates the owners' map cells (modes 3, 4),
-    # so its compulsory bytes include the state traffic and no update kernel runs
-    direct = prob_rule and C in (8, 33, 37, 40, 53, 81, 150) and os.environ.get("SSMAP_DIRECT", "1") != "0"
+    # probability rules: the streaming kernel also updates the owners' map cells (modes 3, 4), so its
+    # compulsory bytes include the state traffic and no update kernel runs (SSMAP_DIRECT=0: staged
+    # rows and k_update_prob instead)
+    direct = prob_rule and os.environ.get("SSMAP_DIRECT", "1") != "0"
     if direct:
         mode += 2
         # per update cell: the fused row read and written (2 * 4 C), label (4) and colour (3) written, and for
@@ -342,9 +343,16 @@ def dominant_kernel(workload, m):
         per_cell = 8 * C + 7 + (12 if "avg_prob" in wl["rule"] else 0)
         dom_bytes += per_cell * m["k_mean"] * E
     # third template argument: how the pooled goal confidence is staged (0: every goal pools one
-    # class, as the 40-class table does; 2: the SegFormer lists, known at compile time)
-    reg = C in (8, 33, 37, 40, 53, 81, 150)
-    name = f"k_stream_reg<{C}, {mode}, {2 if C == 150 else 0}>" if reg else f"k_stream_lds<{min(mode, 2)}>"
+    # class, as the 40-class table does; 2: the SegFormer lists, known at compile time).  Class counts
+    # of the reference's heads have a kernel of their own, the others run the next size up.
+    exact = C in (8, 33, 37, 40, 53, 81, 150)
+    if exact:
+        name = f"k_stream_reg<{C}, {mode}, {2 if C == 150 else 0}>"
+    elif mode in (0, 3, 4):
+        size = next(b for b in (16, 24, 32, 48, 64, 96, 128, 155) if C <= b)
+        name = f"k_stream_reg_upto<{size}, {mode}, 0>"
+    else:
+        name = f"k_stream_lds<{mode}>"
     return name, direct, dom_bytes, (geo_b, s1_b, state_b)
 
 

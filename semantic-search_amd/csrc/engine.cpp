@@ -296,6 +296,8 @@ int ssmap_create(const ssmap_config *cfg, ssmap_engine **out) {
     v.direct_update = (prob_rule && direct_class_count(v.C) && (int64_t)v.C * v.N * 4 < (1ll << 31) &&
                        c.n_schema + 3 <= 64) ? 1 : 0;
     if (const char *x = getenv("SSMAP_DIRECT")) v.direct_update = v.direct_update && atoi(x) != 0;
+    // (the generic kernel has no direct variant: forcing it also selects staged rows + the update kernel)
+    if (const char *x = getenv("SSMAP_GENERIC")) { v.force_generic = atoi(x) != 0; if (v.force_generic) v.direct_update = 0; }
     if (const char *x = getenv("SSMAP_EXP")) v.exp = atoi(x);
     if (const char *x = getenv("SSMAP_EXP_LDS")) v.exp_lds = atoi(x);
     v.local_stride = 4ll * c.max_map_h * c.max_map_w;

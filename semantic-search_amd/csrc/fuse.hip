@@ -219,15 +219,15 @@ struct DirectMaps {
 // occupancy override asks of the cell's new height: the winner kernel has raised the height map
 // and written the ground-truth map already).  update_row, then label and colour.
 template <int UMODE, int CT, int V, int K, typename VecF>
-__device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, float log2_c, bool on, int lane, int cellw,
+__device__ __forceinline__ void direct_cell(const View &v, const DirectMaps &m, int n_cls, float log2_c, bool on, int lane, int cellw,
                                             float w_old, const VecF (&p)[K], VecF (&mv)[K],
                                             const int (&lut_reg)[(CT + 63) / 64], int pal_reg) {
     const int sub = lane & 15;
     const int cell = cellw & (int)kCellMask;
-    const gptr<float> mrow = m.prob + (int64_t)cell * CT;
+    const gptr<float> mrow = m.prob + (int64_t)cell * n_cls;
     int bi;
     float wn, ent_out;
-    update_row<UMODE, V, K>(v, CT, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
+    update_row<UMODE, V, K>(v, n_cls, log2_c, on, sub, mrow, p, mv, w_old, bi, wn, ent_out);
     int sid = __builtin_amdgcn_ds_bpermute((bi & 63) << 2, lut_reg[0]);
 #pragma unroll
     for (int k = 1; k < (CT + 63) / 64; ++k) {
@@ -273,8 +273,11 @@ struct DirectShared {
     int cell[kDirectPre];
     float scale[kDirectPre];   // average family: what turns an owner's parked row into probabilities
 };
-template <int CT>
+// CT: classes the kernel is compiled for; EXACT: the frame has exactly CT classes, otherwise v.C of them
+// (at most CT; the kernel's class registers beyond v.C hold zeros)
+template <int CT, bool EXACT = true>
 struct DirectRows {
+    __device__ __forceinline__ static int classes(const View &v) { return EXACT ? CT : v.C; }
     // one class per lane and step (16 lanes x K steps): 40 classes are 3 elements a lane where
     // float4 units would be 4 (of which 10 lanes in 16 hold data).  The owners of the whole block
     // are pooled: batches of four cells are dealt to the block's waves in turn, so that the rows of
@@ -284,7 +287,7 @@ struct DirectRows {
 #define SSMAP_DIRECT_WIDE_V 2
 #endif
     // (wide rows: two classes per lane and step, half the load and store instructions per cell)
-    static constexpr int V = (CT > 64 && CT % SSMAP_DIRECT_WIDE_V == 0) ? SSMAP_DIRECT_WIDE_V : 1;
+    static constexpr int V = (EXACT && CT > 64 && CT % SSMAP_DIRECT_WIDE_V == 0) ? SSMAP_DIRECT_WIDE_V : 1;   // (a row of v.C classes may start on any word)
     static constexpr int K = (CT + 16 * V - 1) / (16 * V), NB = kDirectPre / 4 / (kRegTile / 64);
     static constexpr int SV = CT % 4 == 0 ? 4 : (CT % 2 == 0 ? 2 : 1);   // widest vector an owner parks its row with
     typedef float VecF __attribute__((ext_vector_type(V)));
@@ -315,15 +318,16 @@ struct DirectRows {
         // (the slots are written again only by a later pass, behind the barriers of this pass's update)
     }
     // every lane loads, from a safe address where it has nothing to do (cell 0, class 0, first pixel)
-    __device__ __forceinline__ void load_rows(int t) {
+    __device__ __forceinline__ void load_rows(const View &v, int t) {
         const int sub = t & 15;
+        const int n_cls = classes(v);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const gptr<const float> mrow = maps.prob + (int64_t)(cell[b] & (int)kCellMask) * CT;
+            const gptr<const float> mrow = maps.prob + (int64_t)(cell[b] & (int)kCellMask) * n_cls;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int c = V * (sub + 16 * k);
-                mv[b][k] = *(gptr<const VecF>)(mrow + (c < CT ? c : 0));
+                mv[b][k] = *(gptr<const VecF>)(mrow + (c < n_cls ? c : 0));
             }
         }
     }
@@ -354,7 +358,7 @@ struct DirectRows {
         brank = base + __popcll(owners & ((1ull << lane) - 1ull));
         exchange(sh, v, t, cellw, 0);
         load_side(avg);
-        load_rows(t);
+        load_rows(v, t);
     }
     template <int UMODE>
     __device__ __forceinline__ void update(DirectShared &sh, const View &v, int t, const float (&x)[CT], float row_scale,
@@ -363,12 +367,13 @@ struct DirectRows {
         if (n_blk == 0) return;   // the same for the whole block
         if (v.exp & 1) return;
         const int lane = t & 63, sub = lane & 15;
-        const float log2_c = log2f((float)CT);
+        const int n_cls = classes(v);
+        const float log2_c = log2f((float)n_cls);
         for (int r0 = 0; r0 < n_blk; r0 += kDirectPre) {
             if (r0 > 0) {   // rare: more owners in the block than were requested ahead
                 exchange(sh, v, t, s_cellw, r0);
                 load_side(UMODE == 1);
-                load_rows(t);
+                load_rows(v, t);
             }
             if (owner && brank >= r0 && brank < r0 + kDirectPre) {
                 float *row = s_rows[brank - r0];
@@ -397,7 +402,7 @@ struct DirectRows {
                 for (int k = 0; k < K; ++k) {
                     const int c = V * (sub + 16 * k);
                     p[k] = *reinterpret_cast<const VecF *>(&s_rows[on[b] ? r : 0][c < CT ? c : 0]);
-                    const bool used = on[b] && c < CT;
+                    const bool used = on[b] && c < n_cls;
 #pragma unroll
                     for (int j = 0; j < V; ++j) {
                         if (UMODE == 1) p[k][j] *= rs;
@@ -405,7 +410,7 @@ struct DirectRows {
                         mv[b][k][j] = used ? mv[b][k][j] : 0.0f;
                     }
                 }
-                direct_cell<UMODE, CT, V, K>(v, maps, log2_c, on[b], lane, cell[b], (UMODE == 1 && on[b]) ? w_old[b] : 0.0f,
+                direct_cell<UMODE, CT, V, K>(v, maps, n_cls, log2_c, on[b], lane, cell[b], (UMODE == 1 && on[b]) ? w_old[b] : 0.0f,
                                           p, mv[b], lut_reg, pal_reg);
             }
             if (r0 + kDirectPre < n_blk) __syncthreads();   // another pass reuses the LDS rows (the same for the whole block)
@@ -421,8 +426,8 @@ struct DirectRows {
 // read once and should not push the map lines out of L2.  (Two or four pixels per thread with
 // wider loads measured slower: the larger register footprint costs more occupancy than the
 // wider requests gain.)
-template <int CT, int MODE, int POOL>
-__global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 128 ? SSMAP_WPE150 : (MODE >= 3 ? SSMAP_WPED : SSMAP_WPE0), CT > 128 ? SSMAP_WPE150 : (MODE == 0 ? SSMAP_WPE0MAX : (MODE >= 3 ? SSMAP_WPEDMAX : 8))))) void k_stream_reg(View v, StreamArgs a) {
+template <int CT, int MODE, int POOL, bool EXACT>
+__device__ __forceinline__ void stream_reg_body(const View &v, const StreamArgs &a) {
     extern __shared__ float s_pool[];   // POOL: [pool_slots][kRegTile], a column per thread
     const int e = blockIdx.y;
     const int t = threadIdx.x;
@@ -431,8 +436,13 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     const int64_t fbase = (int64_t)e * v.N;
     const int boff = active ? pix * 4 : 0;
     const int plane_bytes = v.N * 4;          // C * N * 4 < 2^31 is checked by the host
+    // EXACT: the frame has CT classes.  Otherwise it has v.C <= CT of them: the planes beyond read as
+    // zero (they lie outside the buffer descriptor) and, for logits, count as -inf: exponential 0,
+    // no part in the maximum, the sums, the arg-max or the entropy
+    static_assert(EXACT || MODE == 0 || MODE >= 3, "staged rows are written by the exact variants and the generic kernel");
+    const int n_cls = EXACT ? CT : v.C;
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.in + ((int64_t)e * CT) * v.N), 0, CT * plane_bytes, 0x00020000);
+        const_cast<float *>(a.in + ((int64_t)e * n_cls) * v.N), 0, n_cls * plane_bytes, 0x00020000);
 
     // the class -> schema table, spread over the lanes (lane l holds entries l, l + 64, ...): asked
     // for in front of the class planes and looked up with a lane permute at the end, so that no
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
 #pragma unroll
         for (int k = 0; k < kLutRegs; ++k) {
             const int idx = (t & 63) + 64 * k;
-            lut_reg[k] = v.lut[idx < CT ? idx : 0];
+            lut_reg[k] = v.lut[idx < n_cls ? idx : 0];
         }
     }
     if (DIRECT) {
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
     // (an env without a frame in this batch keeps last step's words: it owns and stages nothing now)
     if (!active || v.poses[e].skip) { cellw = -1; slot = -1; }
     float row_scale = 1.0f;   // what turns x into probabilities (1 / sum while x holds the exponentials)
-    DirectRows<DIRECT ? CT : 4> dr;
+    DirectRows<DIRECT ? CT : 4, EXACT> dr;
     __shared__ DirectShared dsh;
     if constexpr (DIRECT) dr.request(dsh, v, e, t, cellw, UMODE == 1);
     if (a.from_logits) {
@@ -485,6 +495,10 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         // logits of any magnitude give the reference's differences y - max(y); the exponential in
         // base 2: exp(d) = exp2(d log2(e)), exactly 1 at the max
         float m = -INFINITY;
+        if constexpr (!EXACT) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) x[c] = c < n_cls ? x[c] : -INFINITY;
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) { x[c] *= a.inv_t; m = fmaxf(m, x[c]); }
         // arg-max on the way: y - max is +0 exactly at the classes that reach the max and negative
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         }
         const float inv_s = 1.0f / s;   // the class at the max has exp2(0) = 1: the largest probability is inv_s itself
         // (no class at the max: NaN logits; class 0 like an argmax over NaNs)
-        const int bi = (key >> 31) ? 0 : min((int)(key & 0xFFu), CT - 1);
+        const int bi = (key >> 31) ? 0 : min((int)(key & 0xFFu), n_cls - 1);
         float h_bits;   // entropy in bits
         if constexpr (NORM || POOL) {
             // the probabilities are taken for every pixel (staged rows, pooled confidence): formed in place
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
             }
         }
         if (active) {
-            const float unc = h_bits * (0.693147180559945309f / logf((float)CT));
+            const float unc = h_bits * (0.693147180559945309f / logf((float)n_cls));
             // device-scope (write-through) stores: beside the streaming reads they measured 2-3 us
             // faster than plain or nontemporal ones (tools/store_probe.hip)
             // Stage 1 alone (the label rules' steps): device-scope (write-through) stores, 6 us faster
@@ -593,9 +607,10 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
                 if (a.maxp_out) __builtin_nontemporal_store(conf, a.maxp_out + fbase + pix);
             }
             if (a.probs_out) {
-                float *dst = a.probs_out + ((int64_t)e * CT) * v.N + pix;
+                float *dst = a.probs_out + ((int64_t)e * n_cls) * v.N + pix;
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dst[(int64_t)c * v.N] = x[c];
+                for (int c = 0; c < CT; ++c)
+                    if (EXACT || c < n_cls) dst[(int64_t)c * v.N] = x[c];
             }
         }
     }
@@ -661,6 +676,23 @@ __global__ __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu(CT > 1
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Stage 1 alone is fastest with few waves per SIMD (three at 40 classes); narrower kernels take more of
+// them, so that about as many plane loads stay in flight.
+constexpr int stage1_max_waves(int ct) { return ct >= 40 ? SSMAP_WPE0MAX : (120 / ct > 8 ? 8 : 120 / ct); }
+#define SSMAP_STREAM_BOUNDS(CT, MODE) __launch_bounds__(kRegTile) __attribute__((amdgpu_waves_per_eu( \
+    CT > 128 ? SSMAP_WPE150 : (MODE >= 3 ? SSMAP_WPED : SSMAP_WPE0), \
+    CT > 128 ? SSMAP_WPE150 : (MODE == 0 ? stage1_max_waves(CT) : (MODE >= 3 ? SSMAP_WPEDMAX : 8)))))
+// the frame has exactly CT classes
+template <int CT, int MODE, int POOL>
+__global__ SSMAP_STREAM_BOUNDS(CT, MODE) void k_stream_reg(View v, StreamArgs a) {
+    stream_reg_body<CT, MODE, POOL, true>(v, a);
+}
+// the frame has v.C <= CT classes
+template <int CT, int MODE, int POOL>
+__global__ SSMAP_STREAM_BOUNDS(CT, MODE) void k_stream_reg_upto(View v, StreamArgs a) {
+    stream_reg_body<CT, MODE, POOL, false>(v, a);
 }
 
 // ---------------------------------------------------------------- generic (LDS column) kernel
@@ -897,7 +929,7 @@ static void launch_reg_pool(int mode, hipStream_t s, const View &v, const Stream
     if (mode == 0) hipLaunchKernelGGL((k_stream_reg<CT, 0, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_reg<CT, 1, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     else if (mode == 2) hipLaunchKernelGGL((k_stream_reg<CT, 2, POOL>), grid, dim3(kRegTile), lds, s, v, a);
-    else if constexpr (direct_class_count(CT)) {   // direct update of the owners' map cells
+    else if constexpr (exact_class_count(CT)) {   // direct update of the owners' map cells
         if (mode == 3) hipLaunchKernelGGL((k_stream_reg<CT, 3, POOL>), grid, dim3(kRegTile), lds, s, v, a);
         else hipLaunchKernelGGL((k_stream_reg<CT, 4, POOL>), grid, dim3(kRegTile), lds, s, v, a);
     }
@@ -911,6 +943,21 @@ static void launch_reg(int mode, hipStream_t s, const View &v, const StreamArgs 
     } else {
         launch_reg_pool<CT, 0>(mode, s, v, a);
     }
+}
+// Any other class count up to CT: the same kernel compiled for CT class registers, of which the
+// frame's v.C are live (stage 1 alone, or with the direct update; staged rows stay with the
+// generic kernel).
+template <int CT>
+static void launch_reg_upto(int mode, hipStream_t s, const View &v, const StreamArgs &a) {
+    dim3 grid((v.N + kRegTile - 1) / kRegTile, v.E);
+    const bool pool = a.from_logits && !a.pool_trivial;
+    const size_t lds = (pool ? (size_t)(v.pool_slots > 0 ? v.pool_slots : 1) * kRegTile * sizeof(float) : 0) + (size_t)v.exp_lds;
+#define SSMAP_GO(M) do { if (pool) hipLaunchKernelGGL((k_stream_reg_upto<CT, M, 1>), grid, dim3(kRegTile), lds, s, v, a); \
+                         else hipLaunchKernelGGL((k_stream_reg_upto<CT, M, 0>), grid, dim3(kRegTile), lds, s, v, a); } while (0)
+    if (mode == 0) SSMAP_GO(0);
+    else if (mode == 3) SSMAP_GO(3);
+    else SSMAP_GO(4);
+#undef SSMAP_GO
 }
 
 void launch_update_prob(const View &v, const ssmap_frames &f, hipStream_t s) {
@@ -944,7 +991,7 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
     int mode = 0;
     if (fuse) mode = (v.rule == SSMAP_RULE_LOG_ODDS ? 2 : 1) + (v.direct_update ? 2 : 0);
     // the register kernels address a whole frame with 32-bit buffer offsets
-    if ((int64_t)v.C * v.N * 4 < (1ll << 31)) {
+    if ((int64_t)v.C * v.N * 4 < (1ll << 31) && !v.force_generic) {
         switch (v.C) {
             // the class counts of the reference's segmentation heads (EMSANet 8/33/37/40/53/81,
             // SegFormer ADE20k 150); any other count streams through LDS below
@@ -956,6 +1003,19 @@ void launch_stream(const View &v, const ssmap_frames &f, bool fuse, float *probs
             case 81: launch_reg<81>(mode, s, v, a); return;
             case 150: launch_reg<150>(mode, s, v, a); return;
             default: break;
+        }
+        // any other count: the register kernel of the next size up (modes 1 and 2, staged rows, are
+        // the generic kernel's: SSMAP_DIRECT=0)
+        if (mode == 0 || mode >= 3) {
+            if (v.C <= 16) launch_reg_upto<16>(mode, s, v, a);
+            else if (v.C <= 24) launch_reg_upto<24>(mode, s, v, a);
+            else if (v.C <= 32) launch_reg_upto<32>(mode, s, v, a);
+            else if (v.C <= 48) launch_reg_upto<48>(mode, s, v, a);
+            else if (v.C <= 64) launch_reg_upto<64>(mode, s, v, a);
+            else if (v.C <= 96) launch_reg_upto<96>(mode, s, v, a);
+            else if (v.C <= 128) launch_reg_upto<128>(mode, s, v, a);
+            else launch_reg_upto<SSMAP_MAX_CLASSES>(mode, s, v, a);
+            return;
         }
     }
     dim3 grid((v.N + kTile - 1) / kTile, v.E);

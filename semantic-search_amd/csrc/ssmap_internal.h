@@ -129,13 +129,15 @@ struct EnvState {
     uint32_t bound;
 };
 
-// Class counts for which the register streaming kernel has a variant that updates the owners' map
-// cells itself: every count the register kernel is compiled for (the EMSANet heads, the SegFormer
-// ADE20k head and the 8 classes of the tests).
-// At 150 classes the kernel runs at two waves per SIMD and its tail is not hidden (200 us of 700 at
-// 16 envs), but staging the rows costs more: 100 us for their scattered stores beside the streaming
-// reads and 127 us for the update kernel that reads them back from cold caches.
-constexpr bool direct_class_count(int c) { return c == 8 || c == 33 || c == 37 || c == 40 || c == 53 || c == 81 || c == 150; }
+// Class counts whose probability rules are updated by the streaming kernel itself (no staged rows, no
+// update kernel): all of them.  The counts of the reference's segmentation heads (8, 33, 37, 40, 53,
+// 81, 150) have a register kernel compiled for exactly that many classes, any other count runs the
+// kernel of the next size up with its spare class registers idle.  At 150 classes the kernel runs at
+// two waves per SIMD and its tail is not hidden (200 us of 700 at 16 envs), but staging the rows
+// costs more: 100 us for their scattered stores beside the streaming reads and 127 us for the update
+// kernel that reads them back from cold caches.
+constexpr bool direct_class_count(int c) { return c >= 1 && c <= SSMAP_MAX_CLASSES; }
+constexpr bool exact_class_count(int c) { return c == 8 || c == 33 || c == 37 || c == 40 || c == 53 || c == 81 || c == 150; }
 
 // Everything a kernel needs, passed by value.
 struct View {
@@ -203,6 +205,7 @@ struct View {
     // 2 nothing after the owners have parked their rows, 4 all arithmetic but no stores, 8 every row of
     // cell 0, 16 no label / colour / weight stores, 32 no map-row stores
     int32_t exp, exp_lds;
+    int32_t force_generic;     // SSMAP_GENERIC=1 at create: the generic (LDS column) streaming kernel whatever the class count (tests)
 };
 
 __host__ __device__ inline unsigned long long order_f64(double h) {

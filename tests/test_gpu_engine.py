@@ -43,13 +43,18 @@ def _top2_margin(vectors):
     return (srt[..., -1] - srt[..., -2]) / np.maximum(np.abs(srt[..., -1]), 1e-30)
 
 
-@pytest.mark.parametrize("n_classes,temperature", [(40, 3.2), (150, 2.5), (12, 1.0), (53, 2.0), (8, 1.0)])
-def test_stage1_matches_oracle(n_classes, temperature):
+@pytest.mark.parametrize("n_classes,temperature,generic", [(40, 3.2, False), (150, 2.5, False), (12, 1.0, False), (53, 2.0, False),
+                                                           (8, 1.0, False), (21, 3.2, False), (100, 2.5, False), (155, 1.0, False),
+                                                           (12, 1.0, True), (40, 3.2, True)])
+def test_stage1_matches_oracle(n_classes, temperature, generic, monkeypatch):
+    """Class counts with a kernel of their own, counts that run the next size up (12, 21, 100, 155), and
+    the generic LDS-column kernel (SSMAP_GENERIC=1 when the engine is created)."""
     import semantic_search_amd as ssa
+    monkeypatch.setenv("SSMAP_GENERIC", "1" if generic else "0")
     h, w = 120, 160
     rng = np.random.default_rng(n_classes)
     logits = (3.0 * rng.standard_normal((2, n_classes, h, w))).astype(np.float32)
-    lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
+    lut = scenes.schema_lut(n_classes) if n_classes >= 16 else scenes.small_lut(n_classes)
     eng = ssa.MapEngine(2, (h, w), depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
                         prob_aggregate="height_map_argmax", seg_model_n_classes=n_classes,
                         max_map_hw=(100, 100))
@@ -163,7 +168,7 @@ def _run_pair(rule, n_classes, temperature, n_frames, hw, from_logits, attrs=Non
     """Drives the engine (E=1, device-resident inputs) and the oracle over the same frames."""
     import semantic_search_amd as ssa
     h, w = hw
-    lut = scenes.schema_lut(n_classes) if n_classes >= 37 else scenes.small_lut(n_classes)
+    lut = scenes.schema_lut(n_classes) if n_classes >= 16 else scenes.small_lut(n_classes)
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate=rule, seg_model_n_classes=n_classes, filter_goal_prob=filter_goal_prob)
     ref = mo.OracleMapper(schema_lut=lut, path_overlay=False, **kw)
@@ -414,10 +419,13 @@ def test_segformer_style_150_classes_w2():
 
 
 @pytest.mark.parametrize("rule,c,from_logits", [("height_map_log_odds", 37, True), ("height_map_w2_avg_prob", 81, True),
-                                                ("height_map_avg_prob", 53, False), ("height_map_w_avg_prob", 37, False)])
+                                                ("height_map_avg_prob", 53, False), ("height_map_w_avg_prob", 37, False),
+                                                ("height_map_log_odds", 100, True), ("height_map_w2_avg_prob", 155, True),
+                                                ("height_map_avg_prob", 21, False), ("height_map_log_odds", 21, True)])
 def test_other_heads_of_the_segmentation_wrapper(rule, c, from_logits):
-    """The class counts of the reference's other EMSANet heads (infer.py:37-95): the streaming kernel's
-    own update against the oracle, fed logits or probabilities."""
+    """The class counts of the reference's other EMSANet heads (infer.py:37-95) and counts without a
+    kernel of their own (21, 100, 155: the kernel of the next size up): the streaming kernel's own
+    update against the oracle, fed logits or probabilities."""
     eng, maps, ref, log = _run_pair(rule, c, 3.2, 3, (120, 160), from_logits, attrs=dict(entropy_threshold=0.3),
                                     bounds=BOUNDS_480)
     if "log_odds" in rule:
@@ -963,7 +971,7 @@ def test_one_env_of_a_batch_is_reset_while_the_others_go_on(rule):
 @pytest.mark.parametrize("rule,c", [("height_map_log_odds", 40), ("height_map_w2_avg_prob", 40), ("height_map_avg_prob", 8),
                                     ("height_map_w2_avg_prob", 150), ("height_map_log_odds", 150),
                                     ("height_map_log_odds", 37), ("height_map_avg_prob", 33), ("height_map_w_avg_prob", 53),
-                                    ("height_map_w2_avg_prob", 81)])
+                                    ("height_map_w2_avg_prob", 81), ("height_map_avg_prob", 12), ("height_map_log_odds", 6)])
 def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
     """The two homes of the probability rules' update for the class counts with a register kernel: inside the streaming kernel
     (default) and as staged rows + k_update_prob (SSMAP_DIRECT=0 when the engine is created).  Same
@@ -975,8 +983,11 @@ def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
     kw = dict(num_semantic_classes=9, depth_hfov=59.0, depth_range=(0.5, 5.0), probablistic_mapping=True,
               prob_aggregate=rule, seg_model_n_classes=c, max_map_hw=ssa.map_size(bounds, 0.03))
     engs = []
-    for direct in ("1", "0"):
+    # the default, staged rows written by the register kernel (exact class counts only; the others
+    # fall to the generic kernel), staged rows written by the generic LDS-column kernel
+    for direct, generic in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("SSMAP_DIRECT", direct)
+        monkeypatch.setenv("SSMAP_GENERIC", generic)
         eng = ssa.MapEngine(2, (96, 128), **kw)
         eng.set_schema(lut)
         for e in range(2):
@@ -996,12 +1007,13 @@ def test_direct_update_equals_rows_and_update_kernel(rule, c, monkeypatch):
             eng.step(dev("depth", np.float32), np.stack(ag), np.stack(cam), [3, 3],
                      probs=dev("semantic_prob", np.float32), semantic_gt=dev("semantic_gt", np.int32))
             res.append(eng.results())
-        for x, y in zip(*res):
-            assert np.array_equal(x, y), t
+        for other_res in res[1:]:
+            for x, y in zip(res[0], other_res):
+                assert np.array_equal(x, y), t
         assert res[0][2].min() > 100
-    for e in range(2):
+    for e, other_eng in ((e, o) for e in range(2) for o in engs[1:]):
         for nm, m in engs[0].maps[e].items():
-            other = engs[1].maps[e][nm]
+            other = other_eng.maps[e][nm]
             if m.dtype.is_floating_point and "log_odds" not in rule and nm in ("avg_prob_seg_map", "avg_prob_weight_map", "unc_map"):
                 # (w_avg_prob: the weight is 1 - entropy, a difference of nearly equal numbers whose entropy
                 # sums run over two class-to-lane layouts: the parity bar itself, 1e-5 + 1e-6, applies)

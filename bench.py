@@ -42,7 +42,7 @@ WORKLOADS = {
 }
 H, W = 480, 640
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
-# a class count none of the register streaming kernels is compiled for: the generic LDS-column path
+# a class count without a streaming kernel of its own: it runs the kernel of the next size up (24 class registers)
 # other heads of the reference's EMSANet wrapper (infer.py: 37 classes SUNRGB-D; 81 as the widest of them)
 WORKLOADS["log_odds_c37"] = dict(rule="height_map_log_odds", C=37, T=3.2, span=14.39, attrs=dict(entropy_threshold=0.0171))
 WORKLOADS["w2_avg_prob_c81"] = dict(rule="height_map_w2_avg_prob", C=81, T=2.5, span=14.39, attrs=dict(entropy_threshold=0.4820))

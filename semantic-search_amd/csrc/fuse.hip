@@ -46,12 +46,14 @@ constexpr int kStride = kTile + 1;
 constexpr int kStageRows = 8;      // owner rows a wave of the register kernel stages per pass
 
 // One term of an entropy sum in bits: -x log2(x) with the hardware logarithm (v_log_f32, one ulp),
-// 0 at 0, -inf below 0, NaN for NaN (scipy.special.entr).  A denormal x counts as 0: its term is
-// below 1e-35 and the hardware logarithm does not take denormals.  With the accurate logf and a
-// division per class the update of 150-class rows was bound by the vector unit, not by memory.
+// 0 at 0, -inf below 0, NaN for NaN (scipy.special.entr).  The logarithm is taken of max(x, smallest
+// normal): the same product for a normal x, 126 x (below 2e-36, like its true term) for a denormal one,
+// which the instruction does not take.  With the accurate logf and a division per class the update
+// of 150-class rows was bound by the vector unit, not by memory; three selects less per term are
+// still 10 us of the 150-class step.
 __device__ inline float entr_bits(float x) {
-    const float t = -x * __builtin_amdgcn_logf(x);
-    return x >= 1.17549435e-38f ? t : (x >= 0.0f ? 0.0f : (x != x ? x : -INFINITY));
+    const float t = -x * __builtin_amdgcn_logf(x < 1.17549435e-38f ? 1.17549435e-38f : x);   // (NaN: the product carries it)
+    return x < 0.0f ? -INFINITY : t;
 }
 
 // Natural logarithm through the hardware base-2 logarithm (v_log_f32, one ulp), about two ulp in
